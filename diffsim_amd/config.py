@@ -1,0 +1,145 @@
+"""U-Net topology description for the DiffSim scoring path.
+
+Mirrors the fields of diffusers' ``unet/config.json`` that the reference's pipeline relies
+on (reference: diffsim/diffsim.py:82 loads the SD1.5 pipeline; SURVEY.md Appendix A lists
+the SD1.5 values).  Parameter names produced by :func:`unet_param_shapes` are the diffusers
+state-dict keys, so a real ``diffusion_pytorch_model.safetensors`` can be fed unchanged.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+
+@dataclass(frozen=True)
+class UNetConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    down_block_types: Tuple[str, ...] = (
+        "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D")
+    up_block_types: Tuple[str, ...] = (
+        "UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D")
+    layers_per_block: int = 2
+    num_attention_heads: int = 8          # SD1.5 "attention_head_dim": 8 == number of heads
+    cross_attention_dim: int = 768
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    sample_size: int = 64                  # latent side (image side / 8)
+    transformer_layers_per_block: int = 1
+    ctx_len: int = 77
+
+    @property
+    def time_embed_dim(self) -> int:
+        return self.block_out_channels[0] * 4
+
+
+SD15 = UNetConfig()
+#: same channel plan as SD1.5 on an 8x8 latent (64 px image): every kernel shape family of the
+#: real model with tiny M -- the GPU parity workhorse.
+SD15_SMALL = UNetConfig(sample_size=8)
+#: small-channel stand-in with identical topology (fast CPU tests)
+TINY = UNetConfig(block_out_channels=(64, 128, 256, 256), num_attention_heads=4,
+                  cross_attention_dim=96, sample_size=16, ctx_len=13)
+
+
+def _resnet(p: str, cin: int, cout: int, temb: int, out: Dict[str, Tuple[int, ...]]):
+    out[p + "norm1.weight"] = (cin,)
+    out[p + "norm1.bias"] = (cin,)
+    out[p + "conv1.weight"] = (cout, cin, 3, 3)
+    out[p + "conv1.bias"] = (cout,)
+    out[p + "time_emb_proj.weight"] = (cout, temb)
+    out[p + "time_emb_proj.bias"] = (cout,)
+    out[p + "norm2.weight"] = (cout,)
+    out[p + "norm2.bias"] = (cout,)
+    out[p + "conv2.weight"] = (cout, cout, 3, 3)
+    out[p + "conv2.bias"] = (cout,)
+    if cin != cout:
+        out[p + "conv_shortcut.weight"] = (cout, cin, 1, 1)
+        out[p + "conv_shortcut.bias"] = (cout,)
+
+
+def _transformer(p: str, c: int, cfg: UNetConfig, out: Dict[str, Tuple[int, ...]]):
+    out[p + "norm.weight"] = (c,)
+    out[p + "norm.bias"] = (c,)
+    out[p + "proj_in.weight"] = (c, c, 1, 1)
+    out[p + "proj_in.bias"] = (c,)
+    for j in range(cfg.transformer_layers_per_block):
+        q = f"{p}transformer_blocks.{j}."
+        for n in ("norm1", "norm2", "norm3"):
+            out[q + n + ".weight"] = (c,)
+            out[q + n + ".bias"] = (c,)
+        out[q + "attn1.to_q.weight"] = (c, c)
+        out[q + "attn1.to_k.weight"] = (c, c)
+        out[q + "attn1.to_v.weight"] = (c, c)
+        out[q + "attn1.to_out.0.weight"] = (c, c)
+        out[q + "attn1.to_out.0.bias"] = (c,)
+        out[q + "attn2.to_q.weight"] = (c, c)
+        out[q + "attn2.to_k.weight"] = (c, cfg.cross_attention_dim)
+        out[q + "attn2.to_v.weight"] = (c, cfg.cross_attention_dim)
+        out[q + "attn2.to_out.0.weight"] = (c, c)
+        out[q + "attn2.to_out.0.bias"] = (c,)
+        out[q + "ff.net.0.proj.weight"] = (8 * c, c)
+        out[q + "ff.net.0.proj.bias"] = (8 * c,)
+        out[q + "ff.net.2.weight"] = (c, 4 * c)
+        out[q + "ff.net.2.bias"] = (c,)
+    out[p + "proj_out.weight"] = (c, c, 1, 1)
+    out[p + "proj_out.bias"] = (c,)
+
+
+def unet_param_shapes(cfg: UNetConfig) -> Dict[str, Tuple[int, ...]]:
+    """All parameters of the full U-Net, diffusers keys, in forward order."""
+    out: Dict[str, Tuple[int, ...]] = {}
+    ch = cfg.block_out_channels
+    temb = cfg.time_embed_dim
+    out["conv_in.weight"] = (ch[0], cfg.in_channels, 3, 3)
+    out["conv_in.bias"] = (ch[0],)
+    out["time_embedding.linear_1.weight"] = (temb, ch[0])
+    out["time_embedding.linear_1.bias"] = (temb,)
+    out["time_embedding.linear_2.weight"] = (temb, temb)
+    out["time_embedding.linear_2.bias"] = (temb,)
+    prev = ch[0]
+    for i, typ in enumerate(cfg.down_block_types):
+        cin, prev = prev, ch[i]
+        for j in range(cfg.layers_per_block):
+            _resnet(f"down_blocks.{i}.resnets.{j}.", cin if j == 0 else ch[i], ch[i], temb, out)
+            if typ == "CrossAttnDownBlock2D":
+                _transformer(f"down_blocks.{i}.attentions.{j}.", ch[i], cfg, out)
+        if i != len(ch) - 1:
+            out[f"down_blocks.{i}.downsamplers.0.conv.weight"] = (ch[i], ch[i], 3, 3)
+            out[f"down_blocks.{i}.downsamplers.0.conv.bias"] = (ch[i],)
+    c = ch[-1]
+    _resnet("mid_block.resnets.0.", c, c, temb, out)
+    _transformer("mid_block.attentions.0.", c, cfg, out)
+    _resnet("mid_block.resnets.1.", c, c, temb, out)
+    rev = list(reversed(ch))
+    o = rev[0]
+    n = cfg.layers_per_block + 1
+    for i, typ in enumerate(cfg.up_block_types):
+        prv, o = o, rev[i]
+        cin = rev[min(i + 1, len(ch) - 1)]
+        for j in range(n):
+            skip = cin if j == n - 1 else o
+            rin = prv if j == 0 else o
+            _resnet(f"up_blocks.{i}.resnets.{j}.", rin + skip, o, temb, out)
+            if typ == "CrossAttnUpBlock2D":
+                _transformer(f"up_blocks.{i}.attentions.{j}.", o, cfg, out)
+        if i != len(ch) - 1:
+            out[f"up_blocks.{i}.upsamplers.0.conv.weight"] = (o, o, 3, 3)
+            out[f"up_blocks.{i}.upsamplers.0.conv.bias"] = (o,)
+    out["conv_norm_out.weight"] = (ch[0],)
+    out["conv_norm_out.bias"] = (ch[0],)
+    out["conv_out.weight"] = (cfg.out_channels, ch[0], 3, 3)
+    out["conv_out.bias"] = (cfg.out_channels,)
+    return out
+
+
+def skip_channel_plan(cfg: UNetConfig) -> List[int]:
+    """Channels of the 12 skip tensors pushed on the down path."""
+    ch = cfg.block_out_channels
+    skips = [ch[0]]
+    for i in range(len(ch)):
+        skips += [ch[i]] * cfg.layers_per_block
+        if i != len(ch) - 1:
+            skips.append(ch[i])
+    return skips

@@ -1,0 +1,83 @@
+"""Synthetic weights and inputs for the DiffSim scoring path.
+
+No SD1.5 checkpoint or dataset exists offline, so benchmarks and parity tests use seeded
+random weights of the real architecture (diffusers-keyed state dict) and image-like latents.
+Everything is drawn with ``torch.Generator('cpu')`` so the GPU box and the build container
+produce bit-identical tensors.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .config import UNetConfig, unet_param_shapes
+
+
+def make_state_dict(cfg: UNetConfig, seed: int = 0, keys: Optional[Sequence[str]] = None
+                    ) -> Dict[str, torch.Tensor]:
+    """Seeded fp32 state dict.  Variance-preserving uniform init (U(+-sqrt(3/fan_in))) so
+    activations neither vanish nor explode through ~60 layers; ``to_q``/``to_k`` carry gain
+    1.4 so attention logits have std ~2 (non-degenerate softmax; SURVEY.md section 7 "hard parts");
+    norm affine parameters are perturbed away from (1,0) so a dropped gamma/beta is caught.
+    Each tensor has its own generator keyed by its position, so a subset is reproducible."""
+    shapes = unet_param_shapes(cfg)
+    out: Dict[str, torch.Tensor] = {}
+    for idx, (k, shp) in enumerate(shapes.items()):
+        if keys is not None and k not in keys:
+            continue
+        g = torch.Generator("cpu").manual_seed(seed * 1000003 + idx)
+        leaf = k.rsplit(".", 2)
+        is_norm = ".norm" in k or k.startswith("conv_norm_out")
+        if is_norm and k.endswith(".weight"):
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif is_norm and k.endswith(".bias"):
+            t = 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith(".bias"):
+            t = (torch.rand(shp, generator=g) * 2 - 1) * 0.1
+        else:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            gain = 1.4 if (k.endswith("to_q.weight") or k.endswith("to_k.weight")) else 1.0
+            a = gain * math.sqrt(3.0 / fan_in)
+            t = (torch.rand(shp, generator=g) * 2 - 1) * a
+        out[k] = t.to(torch.float32).contiguous()
+    return out
+
+
+def make_context(cfg: UNetConfig, seed: int = 77) -> torch.Tensor:
+    """Stand-in for [CLIP(""), CLIP(prompt)] (diffsim_pipeline.py:125-141): (2, L, Dc) fp32."""
+    g = torch.Generator("cpu").manual_seed(seed)
+    return 0.5 * torch.randn((2, cfg.ctx_len, cfg.cross_attention_dim), generator=g)
+
+
+def _lowfreq(g: torch.Generator, ch: int, side: int, normal: bool) -> torch.Tensor:
+    base = torch.randn((1, ch, 8, 8), generator=g) if normal else torch.rand((1, ch, 8, 8), generator=g)
+    return torch.nn.functional.interpolate(base, size=(side, side), mode="bilinear",
+                                           align_corners=False)
+
+
+def make_pair_latents(cfg: UNetConfig, pair_index: int, base_seed: int = 1234
+                      ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Latents-in synthetic pair i: image A drawn first, then B; each (1,4,s,s) fp32,
+    ``0.75*lowfreq + 0.65*randn`` -- unit variance like real SD latents after the 0.18215
+    scaling (SURVEY.md section 8d proposed 0.18215*(...), whose std of 0.13 is drowned by the
+    t=401 noise and gives no score spread between pairs)."""
+    g = torch.Generator("cpu").manual_seed(base_seed + pair_index)
+    s = cfg.sample_size
+    zs = []
+    for _ in range(2):
+        lf = _lowfreq(g, cfg.in_channels, s, normal=True)
+        hf = torch.randn((1, cfg.in_channels, s, s), generator=g)
+        zs.append(0.75 * lf + 0.65 * hf)
+    return zs[0], zs[1]
+
+
+def draw_pair_noise(seed: int, shape: Sequence[int]) -> List[torch.Tensor]:
+    """The four draws one reference call makes on its single generator, in order:
+    vae-sample(A), vae-sample(B), noise(A), noise(B)
+    (reference: diffsim/diffsim.py:109-113 and diffsim/diffsim_pipeline.py:174-176)."""
+    g = torch.Generator("cpu").manual_seed(int(seed))
+    return [torch.randn(tuple(shape), generator=g, dtype=torch.float32) for _ in range(4)]

@@ -40,7 +40,7 @@ SD15 = UNetConfig()
 SD15_SMALL = UNetConfig(sample_size=8)
 #: small-channel stand-in with identical topology (fast CPU tests)
 TINY = UNetConfig(block_out_channels=(64, 128, 256, 256), num_attention_heads=4,
-                  cross_attention_dim=96, sample_size=16, ctx_len=13)
+                  cross_attention_dim=128, sample_size=16, ctx_len=13)
 
 
 def _resnet(p: str, cin: int, cout: int, temb: int, out: Dict[str, Tuple[int, ...]]):

@@ -1,0 +1,99 @@
+// Internal shared declarations for libdiffsim_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/diffsim_amd.h"
+
+namespace dsim {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define DSIM_HIP_CHECK(expr)                                   \
+    do {                                                       \
+        hipError_t _e = (expr);                                \
+        if (_e != hipSuccess) return DSIM_ERR_HIP;             \
+    } while (0)
+
+static inline size_t dtype_size(int dt) { return dt == DSIM_F32 ? 4 : 2; }
+
+// ---------------------------------------------------------------------------------------------
+// implicit-GEMM (linear / 1x1 conv / 3x3 conv) -- gemm.hip
+//   out[m][n] = epi( sum_k A(m,k) * W[n][k] + bias[n] )
+// A is gathered on the fly from token-major activations:
+//   LINEAR : A(m,k) = k < C0 ? A0[m*C0 + k] : A1[m*C1 + (k-C0)]      (channel concat of two sources)
+//   CONV3  : k = tap*C0 + c ; A(m,k) = X[b][iy][ix][c], zero outside, optional stride 2 /
+//            nearest-2x upsample folded into the index
+// ---------------------------------------------------------------------------------------------
+enum GemmMode { GEMM_LINEAR = 0, GEMM_CONV3 = 1 };
+enum GemmEpi { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_GEGLU = 2 };
+
+struct GemmArgs {
+    const void* A0 = nullptr;
+    const void* A1 = nullptr;
+    int C0 = 0, C1 = 0;
+    int mode = GEMM_LINEAR;
+    int Hin = 0, Win = 0, Hout = 0, Wout = 0;   // CONV3 geometry (Hin/Win = stored input size)
+    int stride = 1, ups = 0;
+    int M = 0, N = 0, K = 0;                    // N counts packed weight rows (2x out cols for GEGLU)
+    const void* W = nullptr;                    // packed [N][K], compute dtype
+    const float* bias = nullptr;                // [N] f32 (packed order) or null
+    int epi = EPI_NONE;
+    const void* residual = nullptr;             // [M][ldo]
+    void* out = nullptr;
+    int ldo = 0;
+    const void* zero_page = nullptr;            // >= 16 zero bytes (padding source)
+};
+int launch_gemm(const GemmArgs& a, int dtype, hipStream_t s);
+
+// weight repack kernels -- pack.hip  (src f32/bf16/f16 diffusers layout -> packed compute dtype)
+int pack_linear(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int K,
+                int geglu_interleave, hipStream_t s);                       // [N][K] -> [N][K]
+int pack_conv3(const void* src, int src_dtype, void* dst, int dst_dtype, int Cout, int Cin,
+               hipStream_t s);                                              // [Co][Ci][3][3] -> [Co][9][Ci]
+int pack_conv_in(const void* src, int src_dtype, float* dst, int Cout, int Cin, hipStream_t s);   // -> f32 [9*Ci][Co]
+int pack_vector(const void* src, int src_dtype, float* dst, int N, int geglu_interleave,
+                hipStream_t s);                                             // any -> f32
+// y[n] = bias[n] + sum_k W[n][k] * act(x[k]) ; all f32, W may be f32/bf16/f16 ; act: 0 id, 1 silu
+int gemv_f32(const void* W, int w_dtype, const void* bias, int b_dtype, const float* x, float* y,
+             int N, int K, int act, hipStream_t s);
+int add_vectors_f32(const float* a, const float* b, float* out, int N, hipStream_t s);
+int timestep_sincos(float* out, int dim, int t, hipStream_t s);
+
+// noising + CFG duplication + conv_in (direct) -- pack.hip
+//   x_t = sa*lat + sb*noise ; out[(img*2+cfg)][pix][co] for cfg in {0,1}
+int prep_conv_in(const float* lat, const float* noise, float sa, float sb, const float* w /*[36][Cout]*/,
+                 const float* bias, void* out, int dtype, int n_img, int Cin, int S, int Cout,
+                 hipStream_t st);
+int convert_f32_to(const float* src, void* dst, int dtype, size_t n, hipStream_t s);
+
+// norms -- norm.hip
+size_t groupnorm_scratch_bytes(int B, int groups);
+int launch_groupnorm(const void* x0, int C0, const void* x1, int C1, const float* gamma,
+                     const float* beta, void* out, int B, int HW, int groups, float eps, int silu,
+                     int dtype, void* scratch, hipStream_t s);
+int launch_layernorm(const void* x, const float* gamma, const float* beta, void* out, int M, int C,
+                     float eps, int dtype, hipStream_t s);
+
+// attention + fused score tail -- attention.hip
+struct AttnArgs {
+    const void* q = nullptr; int ldq = 0;     // [B][Nq] rows of ldq elements, head h at column h*D
+    const void* k = nullptr; const void* v = nullptr; int ldk = 0;   // [Bkv][Nk] rows
+    void* out = nullptr; int ldo = 0;
+    int B = 0, Bkv = 0, H = 0, Nq = 0, Nk = 0, D = 0;
+};
+int launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
+size_t pair_score_scratch_bytes(int n_pairs, int B, int H, int N, int D);
+int launch_pair_score(const void* q, const void* k, const void* v, const int32_t* idx_a,
+                      const int32_t* idx_b, int n_pairs, int B, int H, int N, int D, int dtype,
+                      int similarity, float* out, void* scratch, size_t scratch_bytes, hipStream_t s);
+
+}  // namespace dsim

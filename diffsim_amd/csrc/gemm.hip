@@ -1,0 +1,304 @@
+// Implicit-GEMM MFMA kernel for gfx950: linear / 1x1 conv / 3x3 conv (stride 1|2, folded
+// nearest-2x upsample, channel-concat of two sources) with fused bias / residual / GEGLU
+// epilogues.  One template serves the bf16 production path (v_mfma_f32_32x32x16_bf16) and the
+// fp32 parity path (v_mfma_f32_32x32x2_f32, an exact f32 fma chain).
+//
+// Replaces what the reference dispatches to cuDNN/cuBLAS through diffusers' ResnetBlock2D /
+// Transformer2DModel / Attention / FeedForward modules (control flow
+// in /root/reference/diffsim/hacked_modules.py:17-136, 261-434).
+//
+// Data layout: activations token-major [M][C]; weights packed [N][K] with K contiguous
+// (conv: k = tap*Cin + c).  LDS tiles are [rows][128 B] with the 16-B chunk index XOR-swizzled
+// by (row>>1)&7 so that ds_read_b128 fragment reads are bank-conflict free; tiles are filled by
+// LDS-DMA (global_load_lds_dwordx4), whose lane-linear destination means the swizzle is applied
+// to the per-lane SOURCE address.  Zero padding of conv borders and ragged M/N edges comes from
+// pointing those lanes at a 16-byte zero page.
+#include "common.h"
+
+namespace dsim {
+namespace {
+
+template <typename T> struct Traits;
+template <> struct Traits<bf16> {
+    static constexpr int BK = 64;     // elements per 128-byte LDS row
+    static constexpr int KSUB = 4;    // 16-deep MFMA steps per K tile
+    static constexpr int VEC = 8;     // elements per 16-byte chunk
+};
+template <> struct Traits<float> {
+    static constexpr int BK = 32;
+    static constexpr int KSUB = 2;
+    static constexpr int VEC = 4;
+};
+
+struct FragF32 { f32x4 lo, hi; };
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void load_frag(bf16x8& f, const char* row, int c0, int sw) {
+    f = *reinterpret_cast<const bf16x8*>(row + ((c0 ^ sw) << 4));
+}
+__device__ __forceinline__ void load_frag(FragF32& f, const char* row, int c0, int sw) {
+    f.lo = *reinterpret_cast<const f32x4*>(row + ((c0 ^ sw) << 4));
+    f.hi = *reinterpret_cast<const f32x4*>(row + (((c0 + 1) ^ sw) << 4));
+}
+__device__ __forceinline__ void mma(const bf16x8& a, const bf16x8& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// f32: the 16-deep step is 8 exact-f32 MFMAs of depth 2; lane half h supplies k = 8h + j to
+// MFMA j for both operands, so the k pairing is consistent (any k order is a valid dot product).
+__device__ __forceinline__ void mma(const FragF32& a, const FragF32& b, f32x16& c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.lo[j], b.lo[j], c, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[j], b.hi[j], c, 0, 0, 0);
+}
+template <typename T> struct FragOf { typedef bf16x8 type; };
+template <> struct FragOf<float> { typedef FragF32 type; };
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+
+template <typename T, int BM, int BN, int MODE, bool GEGLU>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p, const int tilesN) {
+    constexpr int BK = Traits<T>::BK;
+    constexpr int KSUB = Traits<T>::KSUB;
+    constexpr int VEC = Traits<T>::VEC;
+    constexpr int TM = BM / 128, TN = BN / 32;
+    constexpr int NA = BM / 32, NB = BN / 32;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    typedef typename FragOf<T>::type Frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware bijective remap: the 8 XCDs take consecutive block ids round-robin; give each
+    // XCD a contiguous run of logical tiles so that tiles sharing an A panel share an L2.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int m0 = (bid / tilesN) * BM, n0 = (bid % tilesN) * BN;
+
+    const int lrow = lane >> 3;                                   // row inside an 8-row DMA piece
+    const int wrow = wave * 8 + lrow;                             // row inside a 32-row group
+    const int cel = ((lane & 7) ^ ((wrow >> 1) & 7)) * VEC;       // swizzled source chunk (elements)
+
+    // ---- per-thread A row state ----------------------------------------------------------
+    int a_iy0[NA], a_ix0[NA];
+    unsigned a_base[NA], a_off[NA];
+    unsigned a_ok = 0;   // bit i: row i valid for the current tap
+    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + i * 32 + wrow;
+        if (MODE == GEMM_CONV3) {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            a_iy0[i] = (m < p.M) ? oy * p.stride - 1 : -(1 << 20);
+            a_ix0[i] = ox * p.stride - 1;
+            a_base[i] = (unsigned)b * (unsigned)(p.Hin * p.Win);
+        } else {
+            a_iy0[i] = a_ix0[i] = 0;
+            a_base[i] = (unsigned)m;
+            if (m < p.M) a_ok |= 1u << i;
+        }
+        a_off[i] = 0;
+    }
+    unsigned b_off[NB];
+    unsigned b_ok = 0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int n = n0 + i * 32 + wrow;
+        b_off[i] = (unsigned)n * (unsigned)p.K + cel;
+        if (n < p.N) b_ok |= 1u << i;
+    }
+    const char* const zp = (const char*)p.zero_page;
+
+    auto stage = [&](int t, int buf) {
+        char* sa = smem + buf * STAGE;
+        char* sb = sa + A_BYTES;
+        const int k0 = t * BK;
+        const char* abase;
+        unsigned koff;
+        if (MODE == GEMM_CONV3) {
+            const int tap = k0 / p.C0;
+            koff = k0 - tap * p.C0;
+            abase = (const char*)p.A0;
+            if (koff == 0) {   // first K tile of a tap: re-derive the gathered pixel of every row
+                const int ky = tap / 3, kx = tap - ky * 3;
+                a_ok = 0;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+                    const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+                    a_ok |= ok ? (1u << i) : 0u;
+                    const unsigned pix = a_base[i] + (unsigned)((iy >> p.ups) * p.Win + (ix >> p.ups));
+                    a_off[i] = pix * (unsigned)p.C0 + cel;
+                }
+            }
+        } else {
+            int cs;
+            if (k0 < p.C0) { abase = (const char*)p.A0; cs = p.C0; koff = k0; }
+            else           { abase = (const char*)p.A1; cs = p.C1; koff = k0 - p.C0; }
+#pragma unroll
+            for (int i = 0; i < NA; ++i) a_off[i] = a_base[i] * (unsigned)cs + cel;
+        }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const char* src = ((a_ok >> i) & 1u) ? abase + (size_t)(a_off[i] + koff) * sizeof(T) : zp;
+            glds16(src, sa + (i * 4 + wave) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const char* src = ((b_ok >> i) & 1u) ? (const char*)p.W + (size_t)(b_off[i] + k0) * sizeof(T) : zp;
+            glds16(src, sb + (i * 4 + wave) * 1024);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = p.K / BK;
+    const int half = lane >> 5;
+    const int sw = (lane >> 1) & 7;                  // == (row>>1)&7 for row = 32*x + (lane&31)
+    const int frow = (lane & 31) * 128;
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) stage(t + 1, cur ^ 1);
+        const char* sa = smem + cur * STAGE + wave * (BM / 4) * 128 + frow;
+        const char* sb = smem + cur * STAGE + A_BYTES + frow;
+#pragma unroll
+        for (int kk = 0; kk < KSUB; ++kk) {
+            const int c0 = (sizeof(T) == 2) ? (2 * kk + half) : (4 * kk + 2 * half);
+            Frag a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) load_frag(a[i], sa + i * 32 * 128, c0, sw);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) load_frag(b[j], sb + j * 32 * 128, c0, sw);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mma(a[i], b[j], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: column on the lane, 16 rows in registers ---------------------------------
+    T* const out = (T*)p.out;
+    const T* const res = (const T*)p.residual;
+    const int mw = m0 + wave * (BM / 4) + 4 * half;
+    if (!GEGLU) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + j * 32 + (lane & 31);
+            if (n >= p.N) continue;
+            const float bv = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (m < p.M) {
+                        float v = acc[i][j][r] + bv;
+                        const size_t o = (size_t)m * p.ldo + n;
+                        if (p.epi == EPI_RESIDUAL) v += to_f32(res[o]);
+                        out[o] = (T)v;
+                    }
+                }
+            }
+        }
+    } else {
+        // packed rows alternate 32-wide blocks: [h-block, g-block]; out column = packed/2
+#pragma unroll
+        for (int j = 0; j < TN; j += 2) {
+            const int nh = n0 + j * 32 + (lane & 31);
+            if (nh >= p.N) continue;
+            const float bh = p.bias ? p.bias[nh] : 0.0f, bg = p.bias ? p.bias[nh + 32] : 0.0f;
+            const int no = (n0 >> 1) + (j >> 1) * 32 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (m < p.M) {
+                        const float hv = acc[i][j][r] + bh, gv = acc[i][j + 1][r] + bg;
+                        out[(size_t)m * p.ldo + no] = (T)(hv * gelu_erf(gv));
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int MODE, bool GEGLU>
+int launch_one(const GemmArgs& a, hipStream_t s) {
+    constexpr int LDS = 2 * (BM + BN) * 128;
+    static bool attr_done = false;   // one handle per device / one host thread per handle
+    auto kern = gemm_kernel<T, BM, BN, MODE, GEGLU>;
+    if (!attr_done) {
+        DSIM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done = true;
+    }
+    const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(256), LDS, s, a, tilesN);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+
+template <typename T>
+int launch_typed(const GemmArgs& a, hipStream_t s) {
+    constexpr int BK = Traits<T>::BK;
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % BK) return DSIM_ERR_INVALID;
+    if (a.mode == GEMM_CONV3) {
+        if (a.C0 % BK || a.K != 9 * a.C0 || a.A1) return DSIM_ERR_INVALID;
+    } else {
+        if (a.C0 % BK || (a.A1 && a.C1 % BK) || a.K != a.C0 + (a.A1 ? a.C1 : 0)) return DSIM_ERR_INVALID;
+    }
+    if (!a.zero_page) return DSIM_ERR_INVALID;
+    // tile choice: 160-wide tiles when N allows (every SD channel count is a multiple of 160),
+    // 256-row tiles once they still give >= one workgroup per CU.
+    const bool n160 = (a.N % 160 == 0) && a.epi != EPI_GEGLU;
+    const int bn = n160 ? 160 : 128;
+    const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + bn - 1) / bn);
+    const bool big = tiles256 >= 256;
+    if (a.epi == EPI_GEGLU) {
+        if (a.mode != GEMM_LINEAR || a.N % 64) return DSIM_ERR_INVALID;
+        return big ? launch_one<T, 256, 128, GEMM_LINEAR, true>(a, s)
+                   : launch_one<T, 128, 128, GEMM_LINEAR, true>(a, s);
+    }
+    if (a.mode == GEMM_CONV3) {
+        if (n160) return big ? launch_one<T, 256, 160, GEMM_CONV3, false>(a, s)
+                             : launch_one<T, 128, 160, GEMM_CONV3, false>(a, s);
+        return big ? launch_one<T, 256, 128, GEMM_CONV3, false>(a, s)
+                   : launch_one<T, 128, 128, GEMM_CONV3, false>(a, s);
+    }
+    if (n160) return big ? launch_one<T, 256, 160, GEMM_LINEAR, false>(a, s)
+                         : launch_one<T, 128, 160, GEMM_LINEAR, false>(a, s);
+    return big ? launch_one<T, 256, 128, GEMM_LINEAR, false>(a, s)
+               : launch_one<T, 128, 128, GEMM_LINEAR, false>(a, s);
+}
+
+}  // namespace
+
+int launch_gemm(const GemmArgs& a, int dtype, hipStream_t s) {
+    if (dtype == DSIM_BF16) return launch_typed<bf16>(a, s);
+    if (dtype == DSIM_F32) return launch_typed<float>(a, s);
+    return DSIM_ERR_INVALID;
+}
+
+}  // namespace dsim

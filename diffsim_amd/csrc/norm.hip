@@ -1,0 +1,299 @@
+// GroupNorm(+SiLU) and LayerNorm for token-major activations on gfx950 (HBM-bound kernels).
+//
+// Replaces torch.nn.GroupNorm / F.silu / torch.nn.LayerNorm as used by diffusers'
+// ResnetBlock2D, Transformer2DModel and BasicTransformerBlock (SURVEY.md Appendix A items 3-5;
+// block control flow: /root/reference/diffsim/hacked_modules.py:39-40, 336-339).
+//
+// GroupNorm runs as two launches over [B][HW][C] (C = C0+C1: the up-path channel concat
+// cat([h, skip]) is read from its two sources and never materialised un-normalised):
+//   1. gn_stats : every workgroup streams a slab of rows with 16-byte loads, each thread owning
+//                 fixed channel slots; per-channel f32 partials -> fixed-order f64 reduction
+//                 per group -> one (sum, sumsq) f64 pair per (batch, slab, group).
+//   2. gn_apply : folds the slab partials in fixed order, then y = (x-mean)*rstd*gamma+beta
+//                 [*sigmoid] with 16-byte loads and stores.
+// No float atomics anywhere: results are bit-reproducible and independent of batch size.
+#include "common.h"
+
+namespace dsim {
+namespace {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAX_SLOTS = 4;     // channel slots (16 B each) a thread may own: C <= 4*256*VEC
+
+template <typename T> struct Vec16;
+template <> struct Vec16<bf16> { typedef bf16x8 type; static constexpr int N = 8; };
+template <> struct Vec16<float> { typedef f32x4 type; static constexpr int N = 4; };
+
+__host__ __device__ inline int gn_chunks(int HW) {
+    int c = HW / 64;
+    return c < 1 ? 1 : (c > 32 ? 32 : c);
+}
+
+template <typename T>
+__device__ __forceinline__ typename Vec16<T>::type load_slot(const T* x0, int C0, const T* x1, int C1,
+                                                             size_t row, int ch) {
+    typedef typename Vec16<T>::type V;
+    return ch < C0 ? *reinterpret_cast<const V*>(x0 + row * C0 + ch)
+                   : *reinterpret_cast<const V*>(x1 + row * C1 + (ch - C0));
+}
+
+// grid (chunks, B)
+template <typename T>
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restrict__ x0, int C0,
+                                                              const T* __restrict__ x1, int C1, int HW,
+                                                              int groups, double* __restrict__ part) {
+    constexpr int VEC = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int C = C0 + C1, S = C / VEC;
+    const int tpr = S < GN_THREADS ? S : GN_THREADS;          // threads per row
+    const int R = GN_THREADS / tpr;                            // rows in flight
+    const int tid = threadIdx.x;
+    const int trow = tid / tpr, tcol = tid - trow * tpr;
+    const int chunks = gridDim.x, chunk = blockIdx.x, b = blockIdx.y;
+    const int r0 = (int)((long)HW * chunk / chunks), r1 = (int)((long)HW * (chunk + 1) / chunks);
+
+    float s1[GN_MAX_SLOTS][VEC], s2[GN_MAX_SLOTS][VEC];
+#pragma unroll
+    for (int k = 0; k < GN_MAX_SLOTS; ++k)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s1[k][e] = s2[k][e] = 0.f;
+
+    if (trow < R) {
+        for (int r = r0 + trow; r < r1; r += R) {
+            const size_t row = (size_t)b * HW + r;
+#pragma unroll
+            for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+                const int slot = tcol + k * tpr;
+                if (slot < S) {
+                    auto v = load_slot<T>(x0, C0, x1, C1, row, slot * VEC);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const float f = (float)v[e];
+                        s1[k][e] += f;
+                        s2[k][e] = fmaf(f, f, s2[k][e]);
+                    }
+                }
+            }
+        }
+    }
+    // per-channel partials of the R row lanes -> LDS [R][C][2]
+    float* lds = reinterpret_cast<float*>(smem);
+    if (trow < R) {
+#pragma unroll
+        for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+            const int slot = tcol + k * tpr;
+            if (slot < S) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    lds[((size_t)trow * C + slot * VEC + e) * 2 + 0] = s1[k][e];
+                    lds[((size_t)trow * C + slot * VEC + e) * 2 + 1] = s2[k][e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // one thread per group, fixed summation order, f64
+    if (tid < groups) {
+        const int cpg = C / groups;
+        double a = 0.0, q = 0.0;
+        for (int rr = 0; rr < R; ++rr)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+                a += (double)lds[((size_t)rr * C + c) * 2 + 0];
+                q += (double)lds[((size_t)rr * C + c) * 2 + 1];
+            }
+        double* o = part + (((size_t)b * chunks + chunk) * groups + tid) * 2;
+        o[0] = a;
+        o[1] = q;
+    }
+}
+
+// grid (row_blocks, B)
+template <typename T, bool SILU>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restrict__ x0, int C0,
+                                                              const T* __restrict__ x1, int C1,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              T* __restrict__ out, int HW, int groups,
+                                                              float eps, int chunks,
+                                                              const double* __restrict__ part) {
+    constexpr int VEC = Vec16<T>::N;
+    typedef typename Vec16<T>::type V;
+    __shared__ float s_mean[64], s_rstd[64];
+    const int C = C0 + C1, S = C / VEC;
+    const int tpr = S < GN_THREADS ? S : GN_THREADS;
+    const int R = GN_THREADS / tpr;
+    const int tid = threadIdx.x;
+    const int trow = tid / tpr, tcol = tid - trow * tpr;
+    const int b = blockIdx.y;
+    const int cpg = C / groups;
+    if (tid < groups) {
+        double a = 0.0, q = 0.0;
+        for (int c = 0; c < chunks; ++c) {
+            const double* o = part + (((size_t)b * chunks + c) * groups + tid) * 2;
+            a += o[0];
+            q += o[1];
+        }
+        const double n = (double)HW * cpg;
+        const double mean = a / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[tid] = (float)mean;
+        s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    if (trow >= R) return;
+    float sc[GN_MAX_SLOTS][VEC], sh[GN_MAX_SLOTS][VEC];
+#pragma unroll
+    for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+        const int slot = tcol + k * tpr;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            if (slot < S) {
+                const int c = slot * VEC + e, g = c / cpg;
+                const float w = gamma[c] * s_rstd[g];
+                sc[k][e] = w;
+                sh[k][e] = beta[c] - s_mean[g] * w;
+            } else {
+                sc[k][e] = sh[k][e] = 0.f;
+            }
+        }
+    }
+    const int rows_per_block = (HW + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = (r0 + rows_per_block < HW) ? r0 + rows_per_block : HW;
+    for (int r = r0 + trow; r < r1; r += R) {
+        const size_t row = (size_t)b * HW + r;
+#pragma unroll
+        for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+            const int slot = tcol + k * tpr;
+            if (slot < S) {
+                V v = load_slot<T>(x0, C0, x1, C1, row, slot * VEC);
+                V o;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float y = fmaf((float)v[e], sc[k][e], sh[k][e]);
+                    if (SILU) y = y / (1.0f + expf(-y));
+                    o[e] = (T)y;
+                }
+                *reinterpret_cast<V*>(out + row * C + slot * VEC) = o;
+            }
+        }
+    }
+}
+
+// one wave per row; 4 rows per workgroup
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ out,
+                                                        int M, int C, float eps) {
+    constexpr int VEC = Vec16<T>::N;
+    constexpr int MAXS = 6;                 // C <= 64*6*VEC (3072 bf16 / 1536 f32)
+    typedef typename Vec16<T>::type V;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int S = C / VEC;
+    const T* xr = x + (size_t)row * C;
+    float v[MAXS][VEC];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXS; ++k) {
+        const int slot = lane + k * 64;
+        if (slot < S) {
+            V t = *reinterpret_cast<const V*>(xr + slot * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { v[k][e] = (float)t[e]; sum += v[k][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[k][e] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXS; ++k) {
+        const int slot = lane + k * 64;
+        if (slot < S) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float d = v[k][e] - mean; sq = fmaf(d, d, sq); }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+    T* orow = out + (size_t)row * C;
+#pragma unroll
+    for (int k = 0; k < MAXS; ++k) {
+        const int slot = lane + k * 64;
+        if (slot < S) {
+            V o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int c = slot * VEC + e;
+                o[e] = (T)fmaf((v[k][e] - mean) * rstd, gamma[c], beta[c]);
+            }
+            *reinterpret_cast<V*>(orow + slot * VEC) = o;
+        }
+    }
+}
+
+template <typename T>
+int gn_typed(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta,
+             void* out, int B, int HW, int groups, float eps, int silu, void* scratch, hipStream_t s) {
+    constexpr int VEC = Vec16<T>::N;
+    const int C = C0 + (x1 ? C1 : 0);
+    if (!x1) C1 = 0;
+    if (C % groups || C0 % VEC || C1 % VEC || groups > 64 || C > GN_MAX_SLOTS * GN_THREADS * VEC)
+        return DSIM_ERR_INVALID;
+    const int S = C / VEC, tpr = S < GN_THREADS ? S : GN_THREADS, R = GN_THREADS / tpr;
+    const int chunks = gn_chunks(HW);
+    const size_t lds = (size_t)R * C * 2 * sizeof(float);
+    if (lds > 64 * 1024) return DSIM_ERR_INVALID;
+    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks, B), dim3(GN_THREADS), lds, s, (const T*)x0, C0,
+                       (const T*)x1, C1, HW, groups, (double*)scratch);
+    int rb = HW / (R * 4);
+    rb = rb < 1 ? 1 : (rb > 64 ? 64 : rb);
+    if (silu)
+        hipLaunchKernelGGL((gn_apply_kernel<T, true>), dim3(rb, B), dim3(GN_THREADS), 0, s, (const T*)x0, C0,
+                           (const T*)x1, C1, gamma, beta, (T*)out, HW, groups, eps, chunks,
+                           (const double*)scratch);
+    else
+        hipLaunchKernelGGL((gn_apply_kernel<T, false>), dim3(rb, B), dim3(GN_THREADS), 0, s, (const T*)x0, C0,
+                           (const T*)x1, C1, gamma, beta, (T*)out, HW, groups, eps, chunks,
+                           (const double*)scratch);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+
+}  // namespace
+
+size_t groupnorm_scratch_bytes(int B, int groups) { return (size_t)B * 32 * groups * 2 * sizeof(double); }
+
+int launch_groupnorm(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta,
+                     void* out, int B, int HW, int groups, float eps, int silu, int dtype, void* scratch,
+                     hipStream_t s) {
+    if (dtype == DSIM_BF16)
+        return gn_typed<bf16>(x0, C0, x1, C1, gamma, beta, out, B, HW, groups, eps, silu, scratch, s);
+    if (dtype == DSIM_F32)
+        return gn_typed<float>(x0, C0, x1, C1, gamma, beta, out, B, HW, groups, eps, silu, scratch, s);
+    return DSIM_ERR_INVALID;
+}
+
+int launch_layernorm(const void* x, const float* gamma, const float* beta, void* out, int M, int C, float eps,
+                     int dtype, hipStream_t s) {
+    const int vec = dtype == DSIM_F32 ? 4 : 8;
+    if (C % vec || C > 64 * 6 * vec) return DSIM_ERR_INVALID;
+    const dim3 grid((M + 3) / 4), block(256);
+    if (dtype == DSIM_BF16)
+        hipLaunchKernelGGL(layernorm_kernel<bf16>, grid, block, 0, s, (const bf16*)x, gamma, beta, (bf16*)out, M, C, eps);
+    else if (dtype == DSIM_F32)
+        hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, s, (const float*)x, gamma, beta, (float*)out, M, C, eps);
+    else
+        return DSIM_ERR_INVALID;
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+
+}  // namespace dsim

@@ -1,0 +1,207 @@
+// Small utility kernels: weight repacking into the engine's layouts, the time-embedding GEMVs,
+// noising + CFG duplication + conv_in, dtype conversion.  None of these is on the per-batch
+// critical path except prep_conv_in (0.02 % of the FLOPs).
+#include "common.h"
+
+namespace dsim {
+namespace {
+
+__device__ __forceinline__ float ld_any(const void* p, int dt, size_t i) {
+    if (dt == DSIM_F32) return ((const float*)p)[i];
+    if (dt == DSIM_BF16) return (float)((const bf16*)p)[i];
+    return (float)((const _Float16*)p)[i];
+}
+__device__ __forceinline__ void st_any(void* p, int dt, size_t i, float v) {
+    if (dt == DSIM_F32) ((float*)p)[i] = v;
+    else ((bf16*)p)[i] = (bf16)v;
+}
+
+// GEGLU row interleave: diffusers' ff.net.0.proj has rows [h (0..F) ; g (F..2F)].  The GEMM's
+// GEGLU epilogue wants packed rows in alternating 32-row blocks [h blk0, g blk0, h blk1, ...].
+__device__ __forceinline__ int geglu_src_row(int packed, int N) {
+    const int F = N >> 1, blk = packed >> 5, within = packed & 31;
+    const int j = (blk >> 1) * 32 + within;
+    return (blk & 1) ? F + j : j;
+}
+
+__global__ void pack_linear_kernel(const void* src, int sdt, void* dst, int ddt, int N, int K, int geglu) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * K) return;
+    const int n = (int)(i / K), k = (int)(i - (size_t)n * K);
+    const int sn = geglu ? geglu_src_row(n, N) : n;
+    st_any(dst, ddt, i, ld_any(src, sdt, (size_t)sn * K + k));
+}
+
+// [Cout][Cin][3][3] -> [Cout][tap = ky*3+kx][Cin]
+__global__ void pack_conv3_kernel(const void* src, int sdt, void* dst, int ddt, int Cout, int Cin) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Cout * 9 * Cin) return;
+    const int ci = (int)(i % Cin);
+    const int tap = (int)((i / Cin) % 9);
+    const int co = (int)(i / ((size_t)9 * Cin));
+    st_any(dst, ddt, i, ld_any(src, sdt, ((size_t)co * Cin + ci) * 9 + tap));
+}
+
+// conv_in for the direct kernel: [Cout][Cin][3][3] -> f32 [tap*Cin + ci][Cout]
+__global__ void pack_conv_in_kernel(const void* src, int sdt, float* dst, int Cout, int Cin) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Cout * 9 * Cin) return;
+    const int co = (int)(i % Cout);
+    const int k = (int)(i / Cout);
+    const int tap = k / Cin, ci = k - tap * Cin;
+    dst[i] = ld_any(src, sdt, ((size_t)co * Cin + ci) * 9 + tap);
+}
+
+__global__ void pack_vector_kernel(const void* src, int sdt, float* dst, int N, int geglu) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    dst[i] = ld_any(src, sdt, geglu ? geglu_src_row(i, N) : i);
+}
+
+// one wave per output row
+__global__ void gemv_kernel(const void* W, int wdt, const void* bias, int bdt, const float* x, float* y, int N, int K,
+                            int act) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        float xv = x[k];
+        if (act == 1) xv = xv / (1.0f + expf(-xv));
+        acc = fmaf(ld_any(W, wdt, (size_t)n * K + k), xv, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) y[n] = acc + (bias ? ld_any(bias, bdt, n) : 0.f);
+}
+
+__global__ void add_vec_kernel(const float* a, const float* b, float* o, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) o[i] = a[i] + b[i];
+}
+
+// diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
+__global__ void timestep_kernel(float* out, int dim, int t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (i >= half) return;
+    const float f = expf(-logf(10000.0f) * (float)i / (float)half);
+    const float e = (float)t * f;
+    out[i] = cosf(e);
+    out[half + i] = sinf(e);
+}
+
+// x_t = sa*lat + sb*noise (NCHW f32), 3x3 conv (pad 1) to Cout, written twice (CFG halves are
+// identical at this point) as token-major [img*2 + cfg][pix][Cout].
+// block = 256 threads handles PIX pixels of one image; w is [tap*Cin + ci][Cout] f32.
+constexpr int PREP_PIX = 16;
+template <typename T>
+__global__ __launch_bounds__(256) void prep_conv_in_kernel(const float* __restrict__ lat, const float* __restrict__ noise,
+                                                           float sa, float sb, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, T* __restrict__ out, int Cin,
+                                                           int S, int Cout) {
+    extern __shared__ float patch[];                // [PREP_PIX][9*Cin]
+    const int img = blockIdx.y, p0 = blockIdx.x * PREP_PIX, K = 9 * Cin, HW = S * S;
+    for (int i = threadIdx.x; i < PREP_PIX * K; i += 256) {
+        const int pp = i / K, k = i - pp * K;
+        const int tap = k / Cin, ci = k - tap * Cin;
+        const int pix = p0 + pp;
+        float v = 0.f;
+        if (pix < HW) {
+            const int y = pix / S + tap / 3 - 1, x = pix % S + tap % 3 - 1;
+            if ((unsigned)y < (unsigned)S && (unsigned)x < (unsigned)S) {
+                const size_t o = (((size_t)img * Cin + ci) * S + y) * S + x;
+                v = sa * lat[o] + sb * noise[o];
+            }
+        }
+        patch[i] = v;
+    }
+    __syncthreads();
+    for (int co = threadIdx.x; co < Cout; co += 256) {
+        float acc[PREP_PIX];
+        const float bv = bias[co];
+#pragma unroll
+        for (int pp = 0; pp < PREP_PIX; ++pp) acc[pp] = bv;
+        for (int k = 0; k < K; ++k) {
+            const float wv = w[(size_t)k * Cout + co];
+#pragma unroll
+            for (int pp = 0; pp < PREP_PIX; ++pp) acc[pp] = fmaf(patch[pp * K + k], wv, acc[pp]);
+        }
+#pragma unroll
+        for (int pp = 0; pp < PREP_PIX; ++pp) {
+            const int pix = p0 + pp;
+            if (pix < HW) {
+                const T v = (T)acc[pp];
+                out[((size_t)(img * 2 + 0) * HW + pix) * Cout + co] = v;
+                out[((size_t)(img * 2 + 1) * HW + pix) * Cout + co] = v;
+            }
+        }
+    }
+}
+
+__global__ void convert_kernel(const float* src, void* dst, int ddt, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) st_any(dst, ddt, i, src[i]);
+}
+
+}  // namespace
+
+int pack_linear(const void* src, int sdt, void* dst, int ddt, int N, int K, int geglu, hipStream_t s) {
+    if (geglu && (N % 64)) return DSIM_ERR_INVALID;
+    const size_t n = (size_t)N * K;
+    hipLaunchKernelGGL(pack_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, sdt, dst, ddt, N, K, geglu);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+int pack_conv3(const void* src, int sdt, void* dst, int ddt, int Cout, int Cin, hipStream_t s) {
+    const size_t n = (size_t)Cout * 9 * Cin;
+    hipLaunchKernelGGL(pack_conv3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, sdt, dst, ddt, Cout, Cin);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+int pack_conv_in(const void* src, int sdt, float* dst, int Cout, int Cin, hipStream_t s) {
+    const size_t n = (size_t)Cout * 9 * Cin;
+    hipLaunchKernelGGL(pack_conv_in_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, sdt, dst, Cout, Cin);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+int pack_vector(const void* src, int sdt, float* dst, int N, int geglu, hipStream_t s) {
+    hipLaunchKernelGGL(pack_vector_kernel, dim3((N + 255) / 256), dim3(256), 0, s, src, sdt, dst, N, geglu);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+int gemv_f32(const void* W, int wdt, const void* bias, int bdt, const float* x, float* y, int N, int K, int act,
+             hipStream_t s) {
+    hipLaunchKernelGGL(gemv_kernel, dim3((N + 3) / 4), dim3(256), 0, s, W, wdt, bias, bdt, x, y, N, K, act);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+int add_vectors_f32(const float* a, const float* b, float* out, int N, hipStream_t s) {
+    hipLaunchKernelGGL(add_vec_kernel, dim3((N + 255) / 256), dim3(256), 0, s, a, b, out, N);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+int timestep_sincos(float* out, int dim, int t, hipStream_t s) {
+    hipLaunchKernelGGL(timestep_kernel, dim3((dim / 2 + 255) / 256), dim3(256), 0, s, out, dim, t);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+int prep_conv_in(const float* lat, const float* noise, float sa, float sb, const float* w, const float* bias, void* out,
+                 int dtype, int n_img, int Cin, int S, int Cout, hipStream_t st) {
+    const dim3 grid((S * S + PREP_PIX - 1) / PREP_PIX, n_img), block(256);
+    const size_t lds = (size_t)PREP_PIX * 9 * Cin * sizeof(float);
+    if (dtype == DSIM_BF16)
+        hipLaunchKernelGGL(prep_conv_in_kernel<bf16>, grid, block, lds, st, lat, noise, sa, sb, w, bias, (bf16*)out, Cin, S, Cout);
+    else if (dtype == DSIM_F32)
+        hipLaunchKernelGGL(prep_conv_in_kernel<float>, grid, block, lds, st, lat, noise, sa, sb, w, bias, (float*)out, Cin, S, Cout);
+    else
+        return DSIM_ERR_INVALID;
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+int convert_f32_to(const float* src, void* dst, int dtype, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, dtype, n);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+
+}  // namespace dsim

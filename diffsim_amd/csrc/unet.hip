@@ -1,0 +1,697 @@
+// U-Net-to-tap graph executor and the C ABI of libdiffsim_amd.
+//
+// Implements, as a sequence of hand-written gfx950 kernels on ONE HIP stream, the sub-graph of
+// diffusers' UNet2DConditionModel that the reference executes before its attention pre-hook
+// fires (DiffSimPipeline.step -> self.unet(...), /root/reference/diffsim/diffsim_pipeline.py:213;
+// hook at /root/reference/diffsim/diffsim.py:43-56).  Block control flow follows the reference's
+// own restatement of it:
+//   CrossAttnDownBlock2D  hacked_modules.py:537-620     UNetMidBlock2DCrossAttn  :622-688
+//   CrossAttnUpBlock2D    hacked_modules.py:438-535     Transformer2DModel       :261-434
+//   BasicTransformerBlock hacked_modules.py:17-136      q/k/v tap                hacked_attn.py:61-77
+// and stops at the tap (nothing downstream of it feeds q/k/v).
+//
+// One `walk()` serves three purposes: PLAN (dry run: peak workspace bytes), RUN (launch), so the
+// planner can never disagree with the executor.  Activations are token-major [B][HW][C] in the
+// compute dtype; the workspace is a caller-provided arena with stack discipline.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+using namespace dsim;
+
+namespace {
+
+struct RawW { const void* p; int dtype; std::vector<int64_t> shape; };
+
+struct Packed { void* p = nullptr; size_t bytes = 0; int rows = 0, cols = 0; };
+
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0, peak = 0;
+    bool dry = true;
+    bool overflow = false;
+    void* alloc(size_t bytes) {
+        const size_t a = (off + 255) & ~(size_t)255;
+        off = a + bytes;
+        if (off > peak) peak = off;
+        if (!dry && off > cap) { overflow = true; return nullptr; }
+        return dry ? (void*)(uintptr_t)(a + 256) : (void*)(base + a);   // non-null dummy when planning
+    }
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+};
+
+struct Act { void* p = nullptr; int C = 0, H = 0, W = 0; };
+
+}  // namespace
+
+struct dsim_unet {
+    dsim_unet_cfg cfg;
+    int dt = DSIM_BF16;
+    bool finalized = false;
+    int timestep = -1;
+    std::map<std::string, RawW> raw;
+    std::map<std::string, Packed> pk;
+    std::vector<void*> owned;
+    void* zero_page = nullptr;
+    float* temb = nullptr;          // [time_embed_dim]
+    float* tscratch = nullptr;      // time-embedding scratch
+    std::string err_key;
+
+    // ---- device memory owned by the handle ------------------------------------------------
+    int dalloc(size_t bytes, void** out) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return DSIM_ERR_HIP;
+        owned.push_back(p);
+        *out = p;
+        return DSIM_OK;
+    }
+    const Packed* find(const std::string& k) {
+        auto it = pk.find(k);
+        if (it == pk.end()) { err_key = k; return nullptr; }
+        return &it->second;
+    }
+};
+
+namespace {
+
+#define CK(expr)                         \
+    do {                                 \
+        int _s = (expr);                 \
+        if (_s != DSIM_OK) return _s;    \
+    } while (0)
+
+bool ends_with(const std::string& s, const char* suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+int64_t numel(const RawW& w) {
+    int64_t n = 1;
+    for (auto d : w.shape) n *= d;
+    return n;
+}
+
+// ---- weight packing (finalize) ---------------------------------------------------------------
+int pack_all(dsim_unet* h, hipStream_t s) {
+    const int dt = h->dt;
+    const size_t es = dtype_size(dt);
+    for (auto& kv : h->raw) {
+        const std::string& key = kv.first;
+        const RawW& w = kv.second;
+        Packed P;
+        if (w.shape.size() == 1) {
+            const int n = (int)w.shape[0];
+            const int geglu = ends_with(key, "ff.net.0.proj.bias");
+            CK(h->dalloc((size_t)n * 4, &P.p));
+            P.rows = n; P.cols = 1; P.bytes = (size_t)n * 4;
+            CK(pack_vector(w.p, w.dtype, (float*)P.p, n, geglu, s));
+            h->pk[key] = P;
+        } else if (w.shape.size() == 4 && w.shape[2] == 3) {
+            const int co = (int)w.shape[0], ci = (int)w.shape[1];
+            if (key == "conv_in.weight") {
+                CK(h->dalloc((size_t)co * ci * 9 * 4, &P.p));
+                P.rows = 9 * ci; P.cols = co;
+                CK(pack_conv_in(w.p, w.dtype, (float*)P.p, co, ci, s));
+            } else {
+                CK(h->dalloc((size_t)co * ci * 9 * es, &P.p));
+                P.rows = co; P.cols = 9 * ci;
+                CK(pack_conv3(w.p, w.dtype, P.p, dt, co, ci, s));
+            }
+            h->pk[key] = P;
+        } else if (w.shape.size() == 2 || (w.shape.size() == 4 && w.shape[2] == 1)) {
+            const int n = (int)w.shape[0], k = (int)w.shape[1];
+            const bool is_q1 = ends_with(key, "attn1.to_q.weight"), is_k1 = ends_with(key, "attn1.to_k.weight"),
+                       is_v1 = ends_with(key, "attn1.to_v.weight");
+            const bool is_k2 = ends_with(key, "attn2.to_k.weight"), is_v2 = ends_with(key, "attn2.to_v.weight");
+            if (is_q1 || is_k1 || is_v1) {
+                // fused [3C][C] = [to_q ; to_k ; to_v]
+                const std::string fk = key.substr(0, key.size() - strlen("to_q.weight")) + "qkv";
+                Packed& F = h->pk[fk];
+                if (!F.p) { CK(h->dalloc((size_t)3 * n * k * es, &F.p)); F.rows = 3 * n; F.cols = k; }
+                const int slot = is_q1 ? 0 : (is_k1 ? 1 : 2);
+                CK(pack_linear(w.p, w.dtype, (char*)F.p + (size_t)slot * n * k * es, dt, n, k, 0, s));
+            } else if (is_k2 || is_v2) {
+                const std::string fk = key.substr(0, key.size() - strlen("to_k.weight")) + "kv";
+                Packed& F = h->pk[fk];
+                if (!F.p) { CK(h->dalloc((size_t)2 * n * k * es, &F.p)); F.rows = 2 * n; F.cols = k; }
+                CK(pack_linear(w.p, w.dtype, (char*)F.p + (size_t)(is_k2 ? 0 : 1) * n * k * es, dt, n, k, 0, s));
+            } else if (ends_with(key, "time_emb_proj.weight") || key.rfind("time_embedding.", 0) == 0) {
+                CK(h->dalloc((size_t)n * k * 4, &P.p));        // kept f32: consumed by the GEMV
+                P.rows = n; P.cols = k;
+                CK(pack_linear(w.p, w.dtype, P.p, DSIM_F32, n, k, 0, s));
+                h->pk[key] = P;
+            } else {
+                const int geglu = ends_with(key, "ff.net.0.proj.weight");
+                CK(h->dalloc((size_t)n * k * es, &P.p));
+                P.rows = n; P.cols = k;
+                CK(pack_linear(w.p, w.dtype, P.p, dt, n, k, geglu, s));
+                h->pk[key] = P;
+            }
+        } else {
+            return DSIM_ERR_INVALID;
+        }
+    }
+    return DSIM_OK;
+}
+
+// ---- the walk ----------------------------------------------------------------------------
+struct Walk {
+    dsim_unet* h;
+    Arena* ar;
+    hipStream_t s;
+    int B2;                 // U-Net batch = 2 * images (CFG)
+    bool run;               // false: plan only
+    void* gn_scratch = nullptr;
+    void* ctx_t = nullptr;  // [2][L][Dc] compute dtype
+    void *q_out = nullptr, *k_out = nullptr, *v_out = nullptr;
+    bool tapped = false;
+
+    size_t es() const { return dtype_size(h->dt); }
+    void* alloc_act(size_t elems) { return ar->alloc(elems * es()); }
+
+#define WGET(var, key)                                   \
+    const Packed* var = h->find(key);                    \
+    if (!var) return DSIM_ERR_MISSING_WEIGHT;
+
+    int gemm(GemmArgs& g) {
+        g.zero_page = h->zero_page;
+        if (!run) return DSIM_OK;
+        return launch_gemm(g, h->dt, s);
+    }
+    int linear(const void* a0, int c0, const void* a1, int c1, const Packed* w, const Packed* b, const void* residual,
+               void* out, int M, int N, int ldo, int epi = -1) {
+        GemmArgs g;
+        g.A0 = a0; g.C0 = c0; g.A1 = a1; g.C1 = a1 ? c1 : 0;
+        g.mode = GEMM_LINEAR;
+        g.M = M; g.N = N; g.K = c0 + (a1 ? c1 : 0);
+        g.W = w->p; g.bias = b ? (const float*)b->p : nullptr;
+        g.epi = epi >= 0 ? epi : (residual ? EPI_RESIDUAL : EPI_NONE);
+        g.residual = residual; g.out = out; g.ldo = ldo;
+        return gemm(g);
+    }
+    int conv3(const Act& x, const Packed* w, const float* bias, const void* residual, void* out, int Cout, int stride,
+              int ups) {
+        GemmArgs g;
+        g.A0 = x.p; g.C0 = x.C; g.mode = GEMM_CONV3;
+        g.Hin = x.H; g.Win = x.W;
+        g.Hout = ups ? x.H * 2 : (stride == 2 ? x.H / 2 : x.H);
+        g.Wout = ups ? x.W * 2 : (stride == 2 ? x.W / 2 : x.W);
+        g.stride = stride; g.ups = ups;
+        g.M = B2 * g.Hout * g.Wout; g.N = Cout; g.K = 9 * x.C;
+        g.W = w->p; g.bias = bias;
+        g.epi = residual ? EPI_RESIDUAL : EPI_NONE;
+        g.residual = residual; g.out = out; g.ldo = Cout;
+        return gemm(g);
+    }
+    int gn(const Act& x0, const Act* x1, const Packed* g, const Packed* b, void* out, float eps, int silu) {
+        if (!run) return DSIM_OK;
+        return launch_groupnorm(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, (const float*)g->p, (const float*)b->p,
+                                out, B2, x0.H * x0.W, h->cfg.norm_num_groups, eps, silu, h->dt, gn_scratch, s);
+    }
+    int ln(const void* x, const Packed* g, const Packed* b, void* out, int M, int C) {
+        if (!run) return DSIM_OK;
+        return launch_layernorm(x, (const float*)g->p, (const float*)b->p, out, M, C, 1e-5f, h->dt, s);
+    }
+    int attn(const AttnArgs& a) {
+        if (!run) return DSIM_OK;
+        return launch_attention(a, h->dt, s);
+    }
+
+    // ResnetBlock2D; x1 = skip tensor concatenated after x0 on channels
+    int resnet(const std::string& p, const Act& x0, const Act* x1, int Cout, Act* out) {
+        const int Cin = x0.C + (x1 ? x1->C : 0), HW = x0.H * x0.W, M = B2 * HW;
+        WGET(n1w, p + "norm1.weight"); WGET(n1b, p + "norm1.bias");
+        WGET(c1w, p + "conv1.weight"); WGET(c1b, p + "conv1.bias_eff");
+        WGET(n2w, p + "norm2.weight"); WGET(n2b, p + "norm2.bias");
+        WGET(c2w, p + "conv2.weight"); WGET(c2b, p + "conv2.bias");
+        out->p = alloc_act((size_t)M * Cout); out->C = Cout; out->H = x0.H; out->W = x0.W;
+        const size_t mk = ar->mark();
+        Act t1{alloc_act((size_t)M * Cin), Cin, x0.H, x0.W};
+        CK(gn(x0, x1, n1w, n1b, t1.p, h->cfg.norm_eps, 1));
+        Act t2{alloc_act((size_t)M * Cout), Cout, x0.H, x0.W};
+        CK(conv3(t1, c1w, (const float*)c1b->p, nullptr, t2.p, Cout, 1, 0));
+        Act t3{alloc_act((size_t)M * Cout), Cout, x0.H, x0.W};
+        CK(gn(t2, nullptr, n2w, n2b, t3.p, h->cfg.norm_eps, 1));
+        const void* res = x0.p;
+        if (Cin != Cout) {
+            WGET(scw, p + "conv_shortcut.weight"); WGET(scb, p + "conv_shortcut.bias");
+            void* sc = alloc_act((size_t)M * Cout);
+            CK(linear(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, scw, scb, nullptr, sc, M, Cout, Cout));
+            res = sc;
+        } else if (x1) {
+            return DSIM_ERR_INVALID;
+        }
+        CK(conv3(t3, c2w, (const float*)c2b->p, res, out->p, Cout, 1, 0));
+        ar->release(mk);
+        return DSIM_OK;
+    }
+
+    // Transformer2DModel with one BasicTransformerBlock; `tap` stops after norm1 and emits q,k,v
+    int transformer(const std::string& p, const Act& x, bool tap, Act* out) {
+        const int C = x.C, HW = x.H * x.W, M = B2 * HW, H = h->cfg.num_heads, D = C / H;
+        const int L = h->cfg.ctx_len, Dc = h->cfg.cross_attention_dim;
+        const std::string b = p + "transformer_blocks.0.";
+        WGET(gnw, p + "norm.weight"); WGET(gnb, p + "norm.bias");
+        WGET(piw, p + "proj_in.weight"); WGET(pib, p + "proj_in.bias");
+        WGET(l1w, b + "norm1.weight"); WGET(l1b, b + "norm1.bias");
+        WGET(qkv, b + "attn1.qkv");
+        if (!tap) { out->p = alloc_act((size_t)M * C); out->C = C; out->H = x.H; out->W = x.W; }
+        const size_t mk = ar->mark();
+        void* t1 = alloc_act((size_t)M * C);
+        CK(gn(x, nullptr, gnw, gnb, t1, 1e-6f, 0));
+        void* hb = alloc_act((size_t)M * C);
+        CK(linear(t1, C, nullptr, 0, piw, pib, nullptr, hb, M, C, C));
+        void* nb = t1;                                   // t1 is dead: reuse it for LayerNorm outputs
+        CK(ln(hb, l1w, l1b, nb, M, C));
+        if (tap) {
+            // hacked_attn.py:61-69: to_q / to_k / to_v, no bias; written [B][N][H*D]
+            Packed wq = *qkv, wk = *qkv, wv = *qkv;
+            wk.p = (char*)qkv->p + (size_t)C * C * es();
+            wv.p = (char*)qkv->p + (size_t)2 * C * C * es();
+            CK(linear(nb, C, nullptr, 0, &wq, nullptr, nullptr, q_out, M, C, C));
+            CK(linear(nb, C, nullptr, 0, &wk, nullptr, nullptr, k_out, M, C, C));
+            CK(linear(nb, C, nullptr, 0, &wv, nullptr, nullptr, v_out, M, C, C));
+            tapped = true;
+            ar->release(mk);
+            return DSIM_OK;
+        }
+        WGET(o1w, b + "attn1.to_out.0.weight"); WGET(o1b, b + "attn1.to_out.0.bias");
+        WGET(l2w, b + "norm2.weight"); WGET(l2b, b + "norm2.bias");
+        WGET(q2w, b + "attn2.to_q.weight"); WGET(kv2, b + "attn2.kv");
+        WGET(o2w, b + "attn2.to_out.0.weight"); WGET(o2b, b + "attn2.to_out.0.bias");
+        WGET(l3w, b + "norm3.weight"); WGET(l3b, b + "norm3.bias");
+        WGET(f1w, b + "ff.net.0.proj.weight"); WGET(f1b, b + "ff.net.0.proj.bias");
+        WGET(f2w, b + "ff.net.2.weight"); WGET(f2b, b + "ff.net.2.bias");
+        WGET(pow_, p + "proj_out.weight"); WGET(pob, p + "proj_out.bias");
+        // self-attention
+        void* big = alloc_act((size_t)M * 4 * C);        // qkv [M][3C], later GEGLU out [M][4C]
+        void* ab = alloc_act((size_t)M * C);
+        CK(linear(nb, C, nullptr, 0, qkv, nullptr, nullptr, big, M, 3 * C, 3 * C));
+        {
+            AttnArgs a;
+            a.q = big; a.ldq = 3 * C;
+            a.k = (char*)big + (size_t)C * es(); a.v = (char*)big + (size_t)2 * C * es(); a.ldk = 3 * C;
+            a.out = ab; a.ldo = C; a.B = B2; a.Bkv = B2; a.H = H; a.Nq = HW; a.Nk = HW; a.D = D;
+            CK(attn(a));
+        }
+        CK(linear(ab, C, nullptr, 0, o1w, o1b, hb, hb, M, C, C));
+        // cross-attention against the prompt context: batch element b uses ctx[b % 2]
+        CK(ln(hb, l2w, l2b, nb, M, C));
+        CK(linear(nb, C, nullptr, 0, q2w, nullptr, nullptr, ab, M, C, C));
+        void* kvb = alloc_act((size_t)2 * L * 2 * C);
+        CK(linear(ctx_t, Dc, nullptr, 0, kv2, nullptr, nullptr, kvb, 2 * L, 2 * C, 2 * C));
+        {
+            AttnArgs a;
+            a.q = ab; a.ldq = C;
+            a.k = kvb; a.v = (char*)kvb + (size_t)C * es(); a.ldk = 2 * C;
+            a.out = big; a.ldo = C; a.B = B2; a.Bkv = 2; a.H = H; a.Nq = HW; a.Nk = L; a.D = D;
+            CK(attn(a));
+        }
+        CK(linear(big, C, nullptr, 0, o2w, o2b, hb, hb, M, C, C));
+        // feed-forward: Linear(C,8C) -> h*gelu(g) fused in the GEMM epilogue -> Linear(4C,C)
+        CK(ln(hb, l3w, l3b, nb, M, C));
+        CK(linear(nb, C, nullptr, 0, f1w, f1b, nullptr, big, M, 8 * C, 4 * C, EPI_GEGLU));
+        CK(linear(big, 4 * C, nullptr, 0, f2w, f2b, hb, hb, M, C, C));
+        CK(linear(hb, C, nullptr, 0, pow_, pob, x.p, out->p, M, C, C));
+        ar->release(mk);
+        return DSIM_OK;
+    }
+
+    int go(const float* lat, const float* noise, float sa, float sb, const float* ctx) {
+        const dsim_unet_cfg& c = h->cfg;
+        const int nl = c.n_levels, S = c.sample_size, ch0 = c.block_out_channels[0];
+        const int L = c.ctx_len, Dc = c.cross_attention_dim;
+        gn_scratch = ar->alloc(groupnorm_scratch_bytes(B2, c.norm_num_groups));
+        ctx_t = ar->alloc((size_t)2 * L * Dc * es());
+        if (run) CK(convert_f32_to(ctx, ctx_t, h->dt, (size_t)2 * L * Dc, s));
+        WGET(ciw, "conv_in.weight"); WGET(cib, "conv_in.bias");
+        Act x{alloc_act((size_t)B2 * S * S * ch0), ch0, S, S};
+        if (run) CK(prep_conv_in(lat, noise, sa, sb, (const float*)ciw->p, (const float*)cib->p, x.p, h->dt, B2 / 2,
+                                 c.in_channels, S, ch0, s));
+        std::vector<Act> skips;
+        skips.push_back(x);
+        // ---- down path (hacked_modules.py:583-618) ---------------------------------------
+        for (int i = 0; i < nl; ++i) {
+            const int co = c.block_out_channels[i];
+            const std::string bp = "down_blocks." + std::to_string(i) + ".";
+            for (int j = 0; j < c.layers_per_block; ++j) {
+                Act r;
+                CK(resnet(bp + "resnets." + std::to_string(j) + ".", x, nullptr, co, &r));
+                x = r;
+                if (c.down_has_attn[i]) {
+                    const bool tap = c.tap_block == DSIM_TAP_DOWN && c.tap_layer == i && j == c.layers_per_block - 1;
+                    Act t;
+                    CK(transformer(bp + "attentions." + std::to_string(j) + ".", x, tap, &t));
+                    if (tap) return DSIM_OK;
+                    x = t;
+                }
+                skips.push_back(x);
+            }
+            if (i != nl - 1) {
+                WGET(dw, bp + "downsamplers.0.conv.weight"); WGET(db, bp + "downsamplers.0.conv.bias");
+                Act d{alloc_act((size_t)B2 * (x.H / 2) * (x.W / 2) * co), co, x.H / 2, x.W / 2};
+                CK(conv3(x, dw, (const float*)db->p, nullptr, d.p, co, 2, 0));
+                x = d;
+                skips.push_back(x);
+            }
+        }
+        // ---- mid (hacked_modules.py:632,664-675) -------------------------------------------
+        {
+            const int cm = c.block_out_channels[nl - 1];
+            Act r;
+            CK(resnet("mid_block.resnets.0.", x, nullptr, cm, &r));
+            x = r;
+            const bool tap = c.tap_block == DSIM_TAP_MID;
+            Act t;
+            CK(transformer("mid_block.attentions.0.", x, tap, &t));
+            if (tap) return DSIM_OK;
+            x = t;
+            CK(resnet("mid_block.resnets.1.", x, nullptr, cm, &r));
+            x = r;
+        }
+        // ---- up path (hacked_modules.py:457-527) -------------------------------------------
+        for (int i = 0; i < nl; ++i) {
+            const int co = c.block_out_channels[nl - 1 - i];
+            const std::string bp = "up_blocks." + std::to_string(i) + ".";
+            const int nres = c.layers_per_block + 1;
+            for (int j = 0; j < nres; ++j) {
+                if (skips.empty()) return DSIM_ERR_INVALID;
+                Act sk = skips.back();
+                skips.pop_back();
+                Act r;
+                CK(resnet(bp + "resnets." + std::to_string(j) + ".", x, &sk, co, &r));
+                x = r;
+                if (c.up_has_attn[i]) {
+                    const bool tap = c.tap_block == DSIM_TAP_UP && c.tap_layer + 1 == i && j == nres - 1;
+                    Act t;
+                    CK(transformer(bp + "attentions." + std::to_string(j) + ".", x, tap, &t));
+                    if (tap) return DSIM_OK;
+                    x = t;
+                }
+            }
+            if (i != nl - 1) {
+                WGET(uw, bp + "upsamplers.0.conv.weight"); WGET(ub, bp + "upsamplers.0.conv.bias");
+                Act u{alloc_act((size_t)B2 * (x.H * 2) * (x.W * 2) * co), co, x.H * 2, x.W * 2};
+                CK(conv3(x, uw, (const float*)ub->p, nullptr, u.p, co, 1, 1));
+                x = u;
+            }
+        }
+        return DSIM_ERR_INVALID;   // the tap was never reached: bad tap_block / tap_layer
+    }
+};
+
+int tap_geometry(const dsim_unet_cfg& c, int* tokens, int* heads, int* hd) {
+    const int nl = c.n_levels;
+    int level;   // resolution level of the tapped block
+    if (c.tap_block == DSIM_TAP_DOWN) {
+        if (c.tap_layer < 0 || c.tap_layer >= nl - 1 || !c.down_has_attn[c.tap_layer]) return DSIM_ERR_INVALID;
+        level = c.tap_layer;
+    } else if (c.tap_block == DSIM_TAP_MID) {
+        level = nl - 1;
+    } else if (c.tap_block == DSIM_TAP_UP) {
+        const int i = c.tap_layer + 1;
+        if (c.tap_layer < 0 || i >= nl || !c.up_has_attn[i]) return DSIM_ERR_INVALID;
+        level = nl - 1 - i;
+    } else {
+        return DSIM_ERR_INVALID;
+    }
+    const int side = c.sample_size >> level;
+    const int C = c.block_out_channels[level];
+    *tokens = side * side;
+    *heads = c.num_heads;
+    *hd = C / c.num_heads;
+    return DSIM_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int dsim_version(void) { return DSIM_ABI_VERSION; }
+
+const char* dsim_strerror(int st) {
+    switch (st) {
+        case DSIM_OK: return "ok";
+        case DSIM_ERR_INVALID: return "invalid argument or unsupported shape";
+        case DSIM_ERR_MISSING_WEIGHT: return "a parameter needed before the tap was never loaded";
+        case DSIM_ERR_WORKSPACE: return "workspace too small";
+        case DSIM_ERR_HIP: return "HIP runtime error";
+        case DSIM_ERR_STATE: return "call order violated";
+        case DSIM_ERR_NO_DEVICE: return "no HIP device";
+        default: return "unknown status";
+    }
+}
+
+int dsim_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int dsim_unet_create(const dsim_unet_cfg* cfg, dsim_unet** out) {
+    if (!cfg || !out) return DSIM_ERR_INVALID;
+    if (cfg->n_levels < 1 || cfg->n_levels > DSIM_MAX_LEVELS) return DSIM_ERR_INVALID;
+    if (cfg->compute_dtype != DSIM_F32 && cfg->compute_dtype != DSIM_BF16) return DSIM_ERR_INVALID;
+    int t, hh, d;
+    CK(tap_geometry(*cfg, &t, &hh, &d));
+    if (dsim_device_count() < 1) return DSIM_ERR_NO_DEVICE;
+    dsim_unet* h = new dsim_unet();
+    h->cfg = *cfg;
+    h->dt = cfg->compute_dtype;
+    if (h->dalloc(256, &h->zero_page) != DSIM_OK || hipMemset(h->zero_page, 0, 256) != hipSuccess) {
+        dsim_unet_destroy(h);
+        return DSIM_ERR_HIP;
+    }
+    *out = h;
+    return DSIM_OK;
+}
+
+void dsim_unet_destroy(dsim_unet* h) {
+    if (!h) return;
+    for (void* p : h->owned) (void)hipFree(p);
+    delete h;
+}
+
+int dsim_unet_load_weight(dsim_unet* h, const char* key, const void* dev_ptr, int dtype, const int64_t* shape, int ndim) {
+    if (!h || !key || !dev_ptr || !shape || ndim < 1 || ndim > 4) return DSIM_ERR_INVALID;
+    if (dtype != DSIM_F32 && dtype != DSIM_BF16 && dtype != DSIM_F16) return DSIM_ERR_INVALID;
+    if (h->finalized) return DSIM_ERR_STATE;
+    RawW w;
+    w.p = dev_ptr; w.dtype = dtype; w.shape.assign(shape, shape + ndim);
+    h->raw[key] = w;
+    return DSIM_OK;
+}
+
+int dsim_unet_finalize(dsim_unet* h, void* stream) {
+    if (!h) return DSIM_ERR_INVALID;
+    if (h->finalized) return DSIM_ERR_STATE;
+    hipStream_t s = (hipStream_t)stream;
+    CK(pack_all(h, s));
+    const int ted = h->cfg.block_out_channels[0] * 4;
+    CK(h->dalloc((size_t)ted * 4, (void**)&h->temb));
+    CK(h->dalloc((size_t)(ted * 2 + h->cfg.block_out_channels[0]) * 4, (void**)&h->tscratch));
+    // conv1.bias_eff buffers (conv1.bias + time_emb_proj(silu(temb))) are filled by set_timestep
+    std::vector<std::string> res;
+    for (auto& kv : h->pk)
+        if (ends_with(kv.first, "time_emb_proj.weight")) res.push_back(kv.first);
+    for (auto& k : res) {
+        const std::string p = k.substr(0, k.size() - strlen("time_emb_proj.weight"));
+        Packed P;
+        P.rows = h->pk[k].rows; P.cols = 1;
+        CK(h->dalloc((size_t)P.rows * 4, &P.p));
+        h->pk[p + "conv1.bias_eff"] = P;
+    }
+    DSIM_HIP_CHECK(hipStreamSynchronize(s));
+    h->raw.clear();
+    h->finalized = true;
+    // make sure every parameter up to the tap exists: dry walk
+    Arena ar;
+    Walk w{h, &ar, s, 2, false};
+    const int st = w.go(nullptr, nullptr, 0.f, 0.f, nullptr);
+    if (st != DSIM_OK) { h->finalized = false; return st; }
+    return DSIM_OK;
+}
+
+int dsim_unet_set_timestep(dsim_unet* h, int t, void* stream) {
+    if (!h || t < 0) return DSIM_ERR_INVALID;
+    if (!h->finalized) return DSIM_ERR_STATE;
+    hipStream_t s = (hipStream_t)stream;
+    const int ch0 = h->cfg.block_out_channels[0], ted = ch0 * 4;
+    float* emb = h->tscratch;              // [ch0]
+    float* h1 = h->tscratch + ch0;         // [ted]
+    float* tp = h1 + ted;                  // [<= ted] per-resnet projection
+    const Packed* w1 = h->find("time_embedding.linear_1.weight");
+    const Packed* b1 = h->find("time_embedding.linear_1.bias");
+    const Packed* w2 = h->find("time_embedding.linear_2.weight");
+    const Packed* b2 = h->find("time_embedding.linear_2.bias");
+    if (!w1 || !b1 || !w2 || !b2) return DSIM_ERR_MISSING_WEIGHT;
+    CK(timestep_sincos(emb, ch0, t, s));
+    CK(gemv_f32(w1->p, DSIM_F32, b1->p, DSIM_F32, emb, h1, ted, ch0, 0, s));
+    CK(gemv_f32(w2->p, DSIM_F32, b2->p, DSIM_F32, h1, h->temb, ted, ted, 1, s));
+    for (auto& kv : h->pk) {
+        if (!ends_with(kv.first, "time_emb_proj.weight")) continue;
+        const std::string p = kv.first.substr(0, kv.first.size() - strlen("time_emb_proj.weight"));
+        const Packed* tb = h->find(p + "time_emb_proj.bias");
+        const Packed* cb = h->find(p + "conv1.bias");
+        const Packed* eff = h->find(p + "conv1.bias_eff");
+        if (!tb || !cb || !eff) return DSIM_ERR_MISSING_WEIGHT;
+        const int n = kv.second.rows;
+        if (n > ted) return DSIM_ERR_INVALID;
+        CK(gemv_f32(kv.second.p, DSIM_F32, tb->p, DSIM_F32, h->temb, tp, n, ted, 1, s));
+        CK(add_vectors_f32((const float*)cb->p, tp, (float*)eff->p, n, s));
+    }
+    h->timestep = t;
+    return DSIM_OK;
+}
+
+size_t dsim_unet_workspace_bytes(const dsim_unet* hc, int n_images) {
+    dsim_unet* h = const_cast<dsim_unet*>(hc);
+    if (!h || !h->finalized || n_images < 1) return 0;
+    Arena ar;
+    Walk w{h, &ar, nullptr, 2 * n_images, false};
+    if (w.go(nullptr, nullptr, 0.f, 0.f, nullptr) != DSIM_OK) return 0;
+    return ar.peak + 256;
+}
+
+int dsim_unet_tap_shape(const dsim_unet* h, int* tokens, int* heads, int* head_dim) {
+    if (!h || !tokens || !heads || !head_dim) return DSIM_ERR_INVALID;
+    return tap_geometry(h->cfg, tokens, heads, head_dim);
+}
+
+int dsim_unet_qkv(dsim_unet* h, const float* latents, const float* noise, float sqrt_abar, float sqrt_1m_abar,
+                  const float* ctx, int n_images, void* q, void* k, void* v, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+    if (!h || !latents || !noise || !ctx || !q || !k || !v || !workspace || n_images < 1) return DSIM_ERR_INVALID;
+    if (!h->finalized || h->timestep < 0) return DSIM_ERR_STATE;
+    Arena ar;
+    ar.dry = false;
+    // align the arena base to 256 B
+    const uintptr_t b0 = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    const size_t lost = b0 - (uintptr_t)workspace;
+    if (workspace_bytes < lost) return DSIM_ERR_WORKSPACE;
+    ar.base = (char*)b0;
+    ar.cap = workspace_bytes - lost;
+    {   // refuse up front instead of failing mid-graph
+        Arena plan;
+        Walk pw{h, &plan, nullptr, 2 * n_images, false};
+        CK(pw.go(nullptr, nullptr, 0.f, 0.f, nullptr));
+        if (plan.peak > ar.cap) return DSIM_ERR_WORKSPACE;
+    }
+    Walk w{h, &ar, (hipStream_t)stream, 2 * n_images, true};
+    w.q_out = q; w.k_out = k; w.v_out = v;
+    CK(w.go(latents, noise, sqrt_abar, sqrt_1m_abar, ctx));
+    if (ar.overflow) return DSIM_ERR_WORKSPACE;
+    return w.tapped ? DSIM_OK : DSIM_ERR_INVALID;
+}
+
+size_t dsim_pair_score_workspace_bytes(int n_pairs, int B, int H, int N, int D) {
+    return pair_score_scratch_bytes(n_pairs, B, H, N, D) + 256;
+}
+
+int dsim_pair_score(const void* q, const void* k, const void* v, const int32_t* idx_a, const int32_t* idx_b, int n_pairs,
+                    int B, int H, int N, int D, int dtype, int similarity, float* out_scores, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+    if (!q || !k || !v || !idx_a || !idx_b || !out_scores || !workspace) return DSIM_ERR_INVALID;
+    if (similarity != 0 && similarity != 1) return DSIM_ERR_INVALID;
+    const uintptr_t b0 = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    const size_t lost = b0 - (uintptr_t)workspace;
+    if (workspace_bytes < lost) return DSIM_ERR_WORKSPACE;
+    return launch_pair_score(q, k, v, idx_a, idx_b, n_pairs, B, H, N, D, dtype, similarity, out_scores, (void*)b0,
+                             workspace_bytes - lost, (hipStream_t)stream);
+}
+
+// ---- single-operator entry points (tests / micro-benchmarks; these allocate and synchronise) ----
+namespace {
+struct Tmp {
+    std::vector<void*> v;
+    ~Tmp() { for (void* p : v) (void)hipFree(p); }
+    void* get(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+        v.push_back(p);
+        return p;
+    }
+};
+}  // namespace
+
+int dsim_op_linear(const void* x, const float* w, const float* bias, const void* residual, void* out, int M, int N,
+                   int K, int dtype, int geglu, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    Tmp t;
+    const int NW = geglu ? 2 * N : N;
+    void* wp = t.get((size_t)NW * K * dtype_size(dtype));
+    float* bp = bias ? (float*)t.get((size_t)NW * 4) : nullptr;
+    void* zp = t.get(256);
+    if (!wp || !zp || (bias && !bp)) return DSIM_ERR_HIP;
+    DSIM_HIP_CHECK(hipMemsetAsync(zp, 0, 256, s));
+    CK(pack_linear(w, DSIM_F32, wp, dtype, NW, K, geglu, s));
+    if (bias) CK(pack_vector(bias, DSIM_F32, bp, NW, geglu, s));
+    GemmArgs g;
+    g.A0 = x; g.C0 = K; g.mode = GEMM_LINEAR; g.M = M; g.N = NW; g.K = K; g.W = wp; g.bias = bp;
+    g.epi = geglu ? EPI_GEGLU : (residual ? EPI_RESIDUAL : EPI_NONE);
+    g.residual = residual; g.out = out; g.ldo = N; g.zero_page = zp;
+    CK(launch_gemm(g, dtype, s));
+    DSIM_HIP_CHECK(hipStreamSynchronize(s));
+    return DSIM_OK;
+}
+
+int dsim_op_conv3x3(const void* x, const float* w, const float* bias, const void* residual, void* out, int B, int H,
+                    int W, int Cin, int Cout, int stride, int upsample, int dtype, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    Tmp t;
+    void* wp = t.get((size_t)Cout * 9 * Cin * dtype_size(dtype));
+    void* zp = t.get(256);
+    if (!wp || !zp) return DSIM_ERR_HIP;
+    DSIM_HIP_CHECK(hipMemsetAsync(zp, 0, 256, s));
+    CK(pack_conv3(w, DSIM_F32, wp, dtype, Cout, Cin, s));
+    GemmArgs g;
+    g.A0 = x; g.C0 = Cin; g.mode = GEMM_CONV3; g.Hin = H; g.Win = W;
+    g.Hout = upsample ? 2 * H : (stride == 2 ? H / 2 : H);
+    g.Wout = upsample ? 2 * W : (stride == 2 ? W / 2 : W);
+    g.stride = stride; g.ups = upsample ? 1 : 0;
+    g.M = B * g.Hout * g.Wout; g.N = Cout; g.K = 9 * Cin; g.W = wp; g.bias = bias;
+    g.epi = residual ? EPI_RESIDUAL : EPI_NONE; g.residual = residual; g.out = out; g.ldo = Cout; g.zero_page = zp;
+    CK(launch_gemm(g, dtype, s));
+    DSIM_HIP_CHECK(hipStreamSynchronize(s));
+    return DSIM_OK;
+}
+
+int dsim_op_groupnorm(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta, void* out,
+                      int B, int HW, int groups, float eps, int silu, int dtype, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    Tmp t;
+    void* sc = t.get(groupnorm_scratch_bytes(B, groups));
+    if (!sc) return DSIM_ERR_HIP;
+    CK(launch_groupnorm(x0, C0, x1, C1, gamma, beta, out, B, HW, groups, eps, silu, dtype, sc, s));
+    DSIM_HIP_CHECK(hipStreamSynchronize(s));
+    return DSIM_OK;
+}
+
+int dsim_op_layernorm(const void* x, const float* gamma, const float* beta, void* out, int M, int C, float eps, int dtype,
+                      void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    CK(launch_layernorm(x, gamma, beta, out, M, C, eps, dtype, s));
+    DSIM_HIP_CHECK(hipStreamSynchronize(s));
+    return DSIM_OK;
+}
+
+int dsim_op_attention(const void* q, int ldq, const void* k, const void* v, int ldk, void* out, int ldo, int B, int Bkv,
+                      int H, int Nq, int Nk, int D, int dtype, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    AttnArgs a;
+    a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldk = ldk; a.out = out; a.ldo = ldo;
+    a.B = B; a.Bkv = Bkv; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D;
+    CK(launch_attention(a, dtype, s));
+    DSIM_HIP_CHECK(hipStreamSynchronize(s));
+    return DSIM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+"""DiffSim scorer with the reference's entry points, backed by the MI355X engine.
+
+Mirrors ``/root/reference/diffsim/diffsim.py``:
+  * ``get_generator``            :16-25
+  * ``DiffSim.__init__``         :80-90   (pipeline load -> here: config + state dict + encoders)
+  * ``prepare_image_latents``    :92-96
+  * ``DiffSim.diffsim``          :98-197  same argument names, returns a (1,) tensor
+and folds in what ``DiffSimPipeline.step`` does around the U-Net call
+(``/root/reference/diffsim/diffsim_pipeline.py:125-221``): prompt context, index -> timestep,
+noise draw, add_noise, CFG duplication.  Deliberate differences (SURVEY.md Appendix C "fix"
+rows, none of which changes a score): the U-Net stops at the tap, no hook is leaked per call,
+the prompt context and image-slot features are cached, both images run in one batch.
+
+The VAE encoder and CLIP text encoder are "next" rows of the scope table: they are
+pluggable (``vae`` with diffusers' ``encode(x).latent_dist.sample(generator)`` surface and an
+``encode_prompt(prompt) -> (2, L, Dc)`` callable).  Without them only the latents-in entry
+points work; the path-based ones raise.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import scheduler as sched
+from .config import SD15, UNetConfig
+from .engine import UNetEngine, pair_score
+from .image import load_image, process_image
+
+
+def get_generator(seed, device="cpu"):
+    if seed is not None:
+        if isinstance(seed, list):
+            generator = [torch.Generator(device).manual_seed(int(s)) for s in seed]
+        else:
+            generator = torch.Generator(device).manual_seed(int(seed))
+    else:
+        generator = None
+    return generator
+
+
+def _norm_layer(target_layer) -> int:
+    # diffsim/diffsim.py:99-100: a single-valued --target_layer is coerced to 0
+    if isinstance(target_layer, int):
+        return target_layer
+    if len(target_layer) == 1:
+        return 0
+    # the reference indexes a ModuleList with the list itself -> TypeError; keep the error
+    raise TypeError("list indices must be integers or slices, not list")
+
+
+class DiffSim:
+    def __init__(self, torch_dtype=torch.bfloat16, device="cuda", ip_adapter=False, *,
+                 unet_config: UNetConfig = SD15, state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                 vae=None, encode_prompt: Optional[Callable[[str], torch.Tensor]] = None,
+                 vae_dtype=torch.float16):
+        if ip_adapter:
+            raise NotImplementedError("IP-Adapter mode is out of scope (SURVEY.md section 2 row 3)")
+        if state_dict is None:
+            raise ValueError("state_dict (diffusers-keyed U-Net weights) is required: no checkpoint is bundled")
+        if torch_dtype == torch.float16:
+            torch_dtype = torch.bfloat16        # the MFMA path computes in bf16; fp32 is the parity mode
+        self.dtype = torch_dtype
+        self.device = torch.device("cuda:0" if device == "cuda" else device)
+        self.ip_adapter = False
+        self.cfg = unet_config
+        self.state_dict = state_dict
+        self.vae = vae
+        self.vae_dtype = vae_dtype
+        self._encode_prompt = encode_prompt
+        self._engines: Dict[Tuple[str, int], UNetEngine] = {}
+        self._ctx: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------------------------------
+    def engine(self, target_block: str, target_layer: int) -> UNetEngine:
+        key = (target_block, int(target_layer))
+        if key not in self._engines:
+            self._engines[key] = UNetEngine(self.cfg, self.state_dict, self.dtype, target_block, target_layer,
+                                            str(self.device))
+        return self._engines[key]
+
+    def context(self, prompt: Union[str, torch.Tensor]) -> torch.Tensor:
+        """[uncond, cond] prompt embeddings (2, L, Dc) f32 on the device; cached per prompt
+        (the reference re-encodes the constant prompt on every call, diffsim_pipeline.py:125)."""
+        if isinstance(prompt, torch.Tensor):
+            return prompt.to(self.device, torch.float32).contiguous()
+        if prompt not in self._ctx:
+            if self._encode_prompt is None:
+                raise RuntimeError("no text encoder plugged in: pass encode_prompt=... or a (2,L,Dc) tensor as prompt")
+            self._ctx[prompt] = self._encode_prompt(prompt).to(self.device, torch.float32).contiguous()
+        return self._ctx[prompt]
+
+    def prepare_image_latents(self, image, vae=None, device=None, generator=None):
+        vae = vae or self.vae
+        if vae is None:
+            raise RuntimeError("no VAE plugged in: use the latents-in entry points (diffsim_latents / score_latent_pairs)")
+        image = image.to(dtype=self.vae_dtype)
+        lat = vae.encode(image).latent_dist.sample(generator=generator)
+        return vae.config.scaling_factor * lat
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def features(self, latents: torch.Tensor, noise: torch.Tensor, prompt, target_block, target_layer, target_step):
+        """latents/noise (n,4,s,s) -> q,k,v [n][2][N][H*D] (compute dtype, on device)."""
+        eng = self.engine(target_block, target_layer)
+        t = sched.timestep_from_index(int(target_step))
+        eng.set_timestep(t)
+        sa, sb = sched.noise_coefficients(t)
+        lat = latents.to(self.device, torch.float32).contiguous()
+        nz = noise.to(self.device, torch.float32).contiguous()
+        return eng.qkv(lat, nz, sa, sb, self.context(prompt))
+
+    @torch.no_grad()
+    def score_latent_pairs(self, latA, latB, noiseA, noiseB, prompt, target_block="up_blocks", target_layer=0,
+                           target_step=600, similarity="cosine", batch_pairs: int = 16) -> torch.Tensor:
+        """Batched latents-in scoring: pair i = (latA[i], latB[i]) -> scores (n,) f32 on device.
+        noiseA/noiseB are (1,4,s,s) (shared by every pair: each reference call reseeds) or (n,4,s,s)."""
+        n = latA.shape[0]
+        eng = self.engine(target_block, target_layer)
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        for i0 in range(0, n, batch_pairs):
+            i1 = min(n, i0 + batch_pairs)
+            m = i1 - i0
+            lat = torch.stack([latA[i0:i1], latB[i0:i1]], dim=1).reshape(2 * m, *latA.shape[1:])
+            nA = noiseA[i0:i1] if noiseA.shape[0] == n else noiseA.expand(m, *noiseA.shape[1:])
+            nB = noiseB[i0:i1] if noiseB.shape[0] == n else noiseB.expand(m, *noiseB.shape[1:])
+            nz = torch.stack([nA, nB], dim=1).reshape(2 * m, *latA.shape[1:])
+            q, k, v = self.features(lat, nz, prompt, target_block, target_layer, target_step)
+            ia = torch.arange(0, 2 * m, 2, dtype=torch.int32, device=self.device)
+            out[i0:i1] = pair_score(q, k, v, ia, ia + 1, eng.heads, similarity)
+        return out
+
+    @torch.no_grad()
+    def diffsim_latents(self, latA, latB, noiseA, noiseB, prompt, target_block="up_blocks", target_layer=0,
+                        target_step=600, similarity="cosine") -> torch.Tensor:
+        return self.score_latent_pairs(latA, latB, noiseA, noiseB, prompt, target_block, _norm_layer(target_layer),
+                                       target_step, similarity)
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def diffsim(self, image_A, image_B, img_size, prompt, target_block, target_layer, target_step, ip_adapter=False,
+                seed="2333", device="cuda", similarity="cosine"):
+        """Same contract as the reference's ``DiffSim.diffsim`` (diffsim/diffsim.py:98-197)."""
+        if ip_adapter:
+            raise NotImplementedError("IP-Adapter mode is out of scope")
+        target_layer = _norm_layer(target_layer)
+        A, B = load_image(image_A), load_image(image_B)
+        tensor_A, tensor_B = process_image(A, img_size), process_image(B, img_size)
+        generator = get_generator(seed, "cpu")                   # reference CPU path: CPU generator
+        latentsA = self.prepare_image_latents(tensor_A, self.vae, device, generator)
+        latentsB = self.prepare_image_latents(tensor_B, self.vae, device, generator)
+        # DiffSimPipeline.step draws the noise right after prepare_latents: A's step first, then B's
+        noiseA = torch.randn(latentsA.shape, generator=generator, dtype=torch.float32)
+        noiseB = torch.randn(latentsB.shape, generator=generator, dtype=torch.float32)
+        return self.score_latent_pairs(latentsA.float(), latentsB.float(), noiseA, noiseB, prompt, target_block,
+                                       target_layer, target_step, similarity)
+
+    @torch.no_grad()
+    def score_pairs(self, pairs: Sequence[Tuple[str, str]], img_size, prompt, target_block, target_layer, target_step,
+                    seed="2333", similarity="cosine", batch_pairs: int = 16) -> torch.Tensor:
+        """Batched equivalent of calling :meth:`diffsim` once per (A, B) path pair."""
+        target_layer = _norm_layer(target_layer)
+        lA, lB = [], []
+        nA = nB = None
+        for pa, pb in pairs:
+            generator = get_generator(seed, "cpu")
+            a = self.prepare_image_latents(process_image(load_image(pa), img_size), self.vae, None, generator)
+            b = self.prepare_image_latents(process_image(load_image(pb), img_size), self.vae, None, generator)
+            if nA is None:   # same seed every call -> the two noise tensors are identical for every pair
+                nA = torch.randn(a.shape, generator=generator, dtype=torch.float32)
+                nB = torch.randn(b.shape, generator=generator, dtype=torch.float32)
+            lA.append(a.float())
+            lB.append(b.float())
+        return self.score_latent_pairs(torch.cat(lA), torch.cat(lB), nA, nB, prompt, target_block, target_layer,
+                                       target_step, similarity, batch_pairs)

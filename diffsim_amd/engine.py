@@ -1,0 +1,225 @@
+"""Python handle over the C ABI: U-Net-to-tap engine, fused score tail and single-op entry points.
+
+PyTorch is used only as the owner of device memory and streams; all arithmetic happens in
+libdiffsim_amd.so.  Every call passes ``tensor.data_ptr()`` and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .config import UNetConfig
+
+_TORCH2DSIM = {torch.float32: _lib.DSIM_F32, torch.bfloat16: _lib.DSIM_BF16, torch.float16: _lib.DSIM_F16}
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.DsimError("tensor is not on the GPU: the engine has no CPU path")
+        if t is not None and not t.is_contiguous():
+            raise _lib.DsimError("tensor must be contiguous")
+
+
+def _cfg_struct(cfg: UNetConfig, dtype: torch.dtype, tap_block: str, tap_layer: int) -> _lib.UNetCfgC:
+    c = _lib.UNetCfgC()
+    n = len(cfg.block_out_channels)
+    c.in_channels, c.n_levels = cfg.in_channels, n
+    for i in range(n):
+        c.block_out_channels[i] = cfg.block_out_channels[i]
+        c.down_has_attn[i] = int(cfg.down_block_types[i] == "CrossAttnDownBlock2D")
+        c.up_has_attn[i] = int(cfg.up_block_types[i] == "CrossAttnUpBlock2D")
+    c.layers_per_block = cfg.layers_per_block
+    c.num_heads = cfg.num_attention_heads
+    c.cross_attention_dim = cfg.cross_attention_dim
+    c.norm_num_groups = cfg.norm_num_groups
+    c.norm_eps = cfg.norm_eps
+    c.sample_size = cfg.sample_size
+    c.ctx_len = cfg.ctx_len
+    c.compute_dtype = _TORCH2DSIM[dtype]
+    c.tap_block = _lib.TAP[tap_block]
+    c.tap_layer = int(tap_layer)
+    return c
+
+
+class UNetEngine:
+    """One handle = one (config, compute dtype, tap) triple with its own packed weights.
+
+    Replaces ``self.unet(...)`` + the attention pre-hook of the reference
+    (diffsim/diffsim_pipeline.py:213-221, diffsim/diffsim.py:43-56, 122-145).
+    """
+
+    def __init__(self, cfg: UNetConfig, state_dict: Dict[str, torch.Tensor], dtype: torch.dtype = torch.bfloat16,
+                 target_block: str = "up_blocks", target_layer: int = 0, device: str = "cuda:0"):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be float32 (parity mode) or bfloat16")
+        self.L = _lib.lib()
+        if not torch.cuda.is_available():
+            raise _lib.DsimError("no GPU visible: the DiffSim engine runs only on the HIP device")
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self.target_block, self.target_layer = target_block, int(target_layer)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            cs = _cfg_struct(cfg, dtype, target_block, target_layer)
+            _lib.check(self.L.dsim_unet_create(C.byref(cs), C.byref(self._h)), "dsim_unet_create")
+            keep = []
+            for k, v in state_dict.items():
+                t = v.detach()
+                if t.dtype not in _TORCH2DSIM:
+                    t = t.float()
+                t = t.to(self.device).contiguous()
+                keep.append(t)
+                shp = (C.c_int64 * t.ndim)(*t.shape)
+                _lib.check(self.L.dsim_unet_load_weight(self._h, k.encode(), t.data_ptr(), _TORCH2DSIM[t.dtype],
+                                                        shp, t.ndim), f"load_weight({k})")
+            torch.cuda.synchronize(self.device)
+            _lib.check(self.L.dsim_unet_finalize(self._h, _stream_ptr()), "dsim_unet_finalize")
+            del keep
+        n, h, d = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self.L.dsim_unet_tap_shape(self._h, C.byref(n), C.byref(h), C.byref(d)), "tap_shape")
+        self.tokens, self.heads, self.head_dim = n.value, h.value, d.value
+        self._ws: Optional[torch.Tensor] = None
+        self._t = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.L.dsim_unet_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_timestep(self, t: int):
+        if self._t != t:
+            with torch.cuda.device(self.device):
+                _lib.check(self.L.dsim_unet_set_timestep(self._h, int(t), _stream_ptr()), "set_timestep")
+            self._t = t
+
+    def workspace_bytes(self, n_images: int) -> int:
+        return int(self.L.dsim_unet_workspace_bytes(self._h, n_images))
+
+    def qkv(self, latents: torch.Tensor, noise: torch.Tensor, sqrt_abar: float, sqrt_1m_abar: float,
+            ctx: torch.Tensor, out: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None):
+        """latents/noise (n,Cin,s,s) f32 cuda; ctx (2,L,Dc) f32 cuda -> q,k,v each
+        [n][2][tokens][heads*head_dim] in the compute dtype."""
+        _require_cuda(latents, noise, ctx)
+        if latents.dtype != torch.float32 or noise.dtype != torch.float32 or ctx.dtype != torch.float32:
+            raise _lib.DsimError("latents, noise and ctx must be float32")
+        n = latents.shape[0]
+        s = self.cfg.sample_size
+        if tuple(latents.shape) != (n, self.cfg.in_channels, s, s) or noise.shape != latents.shape:
+            raise _lib.DsimError(f"latents must be (n,{self.cfg.in_channels},{s},{s})")
+        if tuple(ctx.shape) != (2, self.cfg.ctx_len, self.cfg.cross_attention_dim):
+            raise _lib.DsimError("ctx must be (2, ctx_len, cross_attention_dim)")
+        with torch.cuda.device(self.device):
+            need = self.workspace_bytes(n)
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = None
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            shape = (n, 2, self.tokens, self.heads * self.head_dim)
+            if out is None:
+                out = tuple(torch.empty(shape, dtype=self.dtype, device=self.device) for _ in range(3))
+            q, k, v = out
+            _lib.check(self.L.dsim_unet_qkv(self._h, latents.data_ptr(), noise.data_ptr(), float(sqrt_abar),
+                                            float(sqrt_1m_abar), ctx.data_ptr(), n, q.data_ptr(), k.data_ptr(),
+                                            v.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _stream_ptr()),
+                       "dsim_unet_qkv")
+        return q, k, v
+
+
+def pair_score(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, idx_a: torch.Tensor, idx_b: torch.Tensor,
+               heads: int, similarity: str = "cosine") -> torch.Tensor:
+    """Fused score tail (diffsim/diffsim.py:177-197).  q,k,v: [n_feat][B][N][H*D]; idx: int32 cuda [n_pairs]."""
+    L = _lib.lib()
+    _require_cuda(q, k, v, idx_a, idx_b)
+    if similarity not in ("cosine", "mse"):
+        raise ValueError(similarity)
+    if q.dtype not in (torch.float32, torch.bfloat16) or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise _lib.DsimError("q,k,v must share dtype float32 or bfloat16")
+    if idx_a.dtype != torch.int32 or idx_b.dtype != torch.int32:
+        raise _lib.DsimError("pair indices must be int32")
+    nf, B, N, HD = q.shape
+    D = HD // heads
+    n_pairs = idx_a.numel()
+    out = torch.empty(n_pairs, dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        wsb = int(L.dsim_pair_score_workspace_bytes(n_pairs, B, heads, N, D))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=q.device)
+        _lib.check(L.dsim_pair_score(q.data_ptr(), k.data_ptr(), v.data_ptr(), idx_a.data_ptr(), idx_b.data_ptr(),
+                                     n_pairs, B, heads, N, D, _TORCH2DSIM[q.dtype], 0 if similarity == "cosine" else 1,
+                                     out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr()), "dsim_pair_score")
+    return out
+
+
+# ---- single-operator entry points (kernel-level parity tests) -----------------------------------
+def op_linear(x, w, bias=None, residual=None, geglu=False):
+    L = _lib.lib()
+    _require_cuda(x, w, bias, residual)
+    M, K = x.shape
+    N = w.shape[0] // 2 if geglu else w.shape[0]
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    _lib.check(L.dsim_op_linear(x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K,
+                                _TORCH2DSIM[x.dtype], int(geglu), _stream_ptr()), "op_linear")
+    return out
+
+
+def op_conv3x3(x, w, bias=None, residual=None, stride=1, upsample=False):
+    """x: [B][H][W][Cin] token-major; w: [Cout][Cin][3][3] f32."""
+    L = _lib.lib()
+    _require_cuda(x, w, bias, residual)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    Ho, Wo = (2 * H, 2 * W) if upsample else ((H // 2, W // 2) if stride == 2 else (H, W))
+    out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    _lib.check(L.dsim_op_conv3x3(x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), B, H, W, Cin,
+                                 Cout, stride, int(upsample), _TORCH2DSIM[x.dtype], _stream_ptr()), "op_conv3x3")
+    return out
+
+
+def op_groupnorm(x0, x1, gamma, beta, groups, eps, silu):
+    """x0: [B][HW][C0], x1: optional [B][HW][C1] (channel concat)."""
+    L = _lib.lib()
+    _require_cuda(x0, x1, gamma, beta)
+    B, HW, C0 = x0.shape
+    C1 = 0 if x1 is None else x1.shape[2]
+    out = torch.empty((B, HW, C0 + C1), dtype=x0.dtype, device=x0.device)
+    _lib.check(L.dsim_op_groupnorm(x0.data_ptr(), C0, _ptr(x1), C1, gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                   B, HW, groups, float(eps), int(silu), _TORCH2DSIM[x0.dtype], _stream_ptr()),
+               "op_groupnorm")
+    return out
+
+
+def op_layernorm(x, gamma, beta, eps=1e-5):
+    L = _lib.lib()
+    _require_cuda(x, gamma, beta)
+    M, Cc = x.shape
+    out = torch.empty_like(x)
+    _lib.check(L.dsim_op_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), M, Cc, float(eps),
+                                   _TORCH2DSIM[x.dtype], _stream_ptr()), "op_layernorm")
+    return out
+
+
+def op_attention(q, k, v, heads):
+    """q: [B][Nq][H*D]; k,v: [Bkv][Nk][H*D] -> [B][Nq][H*D]."""
+    L = _lib.lib()
+    _require_cuda(q, k, v)
+    B, Nq, HD = q.shape
+    Bkv, Nk, _ = k.shape
+    out = torch.empty_like(q)
+    _lib.check(L.dsim_op_attention(q.data_ptr(), HD, k.data_ptr(), v.data_ptr(), HD, out.data_ptr(), HD, B, Bkv, heads,
+                                   Nq, Nk, HD // heads, _TORCH2DSIM[q.dtype], _stream_ptr()), "op_attention")
+    return out

@@ -1,0 +1,42 @@
+"""Host-side scheduler arithmetic of the one-step pipeline.
+
+Mirrors what ``DiffSimPipeline.step`` gets from diffusers' PNDMScheduler with SD1.5's
+scheduler_config (reference call sites: diffsim/diffsim_pipeline.py:153-157 ``timesteps[i]``
+and :177-183 ``scheduler.add_noise``; semantics: SURVEY.md Appendix A item 10).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def alphas_cumprod(num_train_timesteps: int = 1000, beta_start: float = 0.00085,
+                   beta_end: float = 0.012) -> torch.Tensor:
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps,
+                           dtype=torch.float32) ** 2          # "scaled_linear"
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+def pndm_timesteps(num_inference_steps: int = 1000, num_train_timesteps: int = 1000,
+                   steps_offset: int = 1) -> np.ndarray:
+    """``set_timesteps`` with skip_prk_steps: [1000, 999, 999, 998, ..., 1] (N+1 entries)."""
+    ratio = num_train_timesteps // num_inference_steps
+    t = (np.arange(0, num_inference_steps) * ratio).round() + steps_offset
+    return np.concatenate([t[:-1], t[-2:-1], t[-1:]])[::-1].astype(np.int64).copy()
+
+
+def timestep_from_index(target_step: int, num_inference_steps: int = 1000) -> int:
+    """--target_step is an INDEX into the table above (600 -> t = 401)."""
+    ts = pndm_timesteps(num_inference_steps)
+    if not 0 <= target_step < len(ts):
+        raise IndexError(f"target_step {target_step} outside the {len(ts)}-entry timestep table")
+    t = int(ts[target_step])
+    if t >= 1000:
+        # index 0 -> t = 1000 indexes past alphas_cumprod in the reference (IndexError there too)
+        raise IndexError("target_step 0 maps to t=1000, outside the 1000-entry alphas_cumprod table")
+    return t
+
+
+def noise_coefficients(t: int):
+    ac = alphas_cumprod()
+    return float(ac[t] ** 0.5), float((1.0 - ac[t]) ** 0.5)

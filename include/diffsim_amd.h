@@ -1,0 +1,147 @@
+/*
+ * diffsim_amd.h -- C ABI of the MI355X-native DiffSim scoring engine (libdiffsim_amd.so).
+ *
+ * The reference (showlab/DiffSim) has no FFI: its seam is Python.  These entry points are
+ * what a binding for the reference's hot path would call; each cites the reference
+ * interface it replaces.  Conventions:
+ *   - plain pointers and sizes only; every tensor (including the workspace) is allocated
+ *     by the caller (PyTorch-ROCm in the shipped wrapper) and passed as a device pointer;
+ *   - the callee never allocates after dsim_unet_finalize(), never frees caller memory,
+ *     never synchronises the stream and never throws: it returns 0 or a negative
+ *     dsim_status code (dsim_strerror() gives the text);
+ *   - one handle per device, one host thread per handle, re-entrant across handles;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).
+ *
+ * Layouts: activations are token-major ("NHWC"): [batch][pixel][channel].  Q/K/V leave the
+ * engine as [batch][token][head*head_dim] -- the same memory the reference's non-contiguous
+ * (B,H,N,D) views alias (diffsim/hacked_attn.py:74-77).
+ */
+#ifndef DIFFSIM_AMD_H
+#define DIFFSIM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSIM_ABI_VERSION 1
+
+typedef enum dsim_status {
+    DSIM_OK = 0,
+    DSIM_ERR_INVALID = -1,      /* bad argument / unsupported shape */
+    DSIM_ERR_MISSING_WEIGHT = -2,
+    DSIM_ERR_WORKSPACE = -3,    /* workspace too small */
+    DSIM_ERR_HIP = -4,          /* a HIP runtime call failed */
+    DSIM_ERR_STATE = -5,        /* call order violated (e.g. qkv before finalize) */
+    DSIM_ERR_NO_DEVICE = -6
+} dsim_status;
+
+typedef enum dsim_dtype { DSIM_F32 = 0, DSIM_BF16 = 1, DSIM_F16 = 2 } dsim_dtype;
+
+/* where the hooked attn1 sits: diffsim/diffsim.py:122-145
+ *   DOWN: unet.down_blocks[:-1][layer]   MID: unet.mid_block   UP: unet.up_blocks[1:][layer]
+ * always ...attentions[-1].transformer_blocks[-1].attn1                                   */
+typedef enum dsim_tap_block { DSIM_TAP_DOWN = 0, DSIM_TAP_MID = 1, DSIM_TAP_UP = 2 } dsim_tap_block;
+
+#define DSIM_MAX_LEVELS 4
+
+/* Subset of diffusers' unet/config.json the path depends on. */
+typedef struct dsim_unet_cfg {
+    int32_t in_channels;                          /* 4 */
+    int32_t n_levels;                             /* 4 */
+    int32_t block_out_channels[DSIM_MAX_LEVELS];  /* 320,640,1280,1280 */
+    int32_t down_has_attn[DSIM_MAX_LEVELS];       /* 1,1,1,0  (CrossAttnDownBlock2D vs DownBlock2D) */
+    int32_t up_has_attn[DSIM_MAX_LEVELS];         /* 0,1,1,1 */
+    int32_t layers_per_block;                     /* 2 */
+    int32_t num_heads;                            /* 8 */
+    int32_t cross_attention_dim;                  /* 768 */
+    int32_t norm_num_groups;                      /* 32 */
+    float   norm_eps;                             /* 1e-5 (ResnetBlock2D); Transformer2D GN uses 1e-6 */
+    int32_t sample_size;                          /* latent side: 64 for 512 px */
+    int32_t ctx_len;                              /* 77 */
+    int32_t compute_dtype;                        /* dsim_dtype: DSIM_F32 (parity mode) or DSIM_BF16 */
+    int32_t tap_block;                            /* dsim_tap_block */
+    int32_t tap_layer;                            /* index after the reference's slicing */
+} dsim_unet_cfg;
+
+typedef struct dsim_unet dsim_unet;
+
+int         dsim_version(void);
+const char* dsim_strerror(int status);
+/* number of visible HIP devices (does not initialise a context beyond the count query) */
+int         dsim_device_count(void);
+
+/* ---- U-Net-to-tap engine: replaces DiffSimPipeline.step()'s `self.unet(...)` call
+ *      (diffsim/diffsim_pipeline.py:213-221) plus the pre-hook that stashes q,k,v
+ *      (diffsim/diffsim.py:43-56 -> diffsim/hacked_attn.py:61-77). ---------------------- */
+int  dsim_unet_create(const dsim_unet_cfg* cfg, dsim_unet** out);
+void dsim_unet_destroy(dsim_unet* h);
+
+/* Hand one parameter over under its diffusers state-dict key (e.g.
+ * "down_blocks.0.resnets.0.conv1.weight").  `dev_ptr` is borrowed until dsim_unet_finalize()
+ * returns; src dtype may be f32, bf16 or f16; shape is the diffusers shape.  Parameters
+ * that lie after the tap are accepted and ignored. */
+int  dsim_unet_load_weight(dsim_unet* h, const char* key, const void* dev_ptr, int dtype,
+                           const int64_t* shape, int ndim);
+/* Repack every parameter up to the tap into the engine's own device buffers (conv weights
+ * [Cout][3][3][Cin], fused QKV / KV, GEGLU-interleaved FF).  Allocates; synchronises `stream`. */
+int  dsim_unet_finalize(dsim_unet* h, void* stream);
+/* Diffusion timestep t (an actual timestep, not the reference's --target_step index; the
+ * wrapper maps index -> t through the PNDM table, diffsim/diffsim_pipeline.py:153-157).
+ * Pre-computes the time embedding and every ResnetBlock2D time_emb_proj (t is constant over a
+ * run).  Enqueues on `stream`. */
+int  dsim_unet_set_timestep(dsim_unet* h, int t, void* stream);
+
+size_t dsim_unet_workspace_bytes(const dsim_unet* h, int n_images);
+
+/* One noised U-Net forward to the tap for n_images latents, each duplicated for
+ * classifier-free guidance ([uncond, cond], diffsim/diffsim_pipeline.py:208):
+ *   latents, noise : f32 [n_images][C_in][s][s]  (NCHW, as the reference holds them)
+ *   x_t = sqrt_abar*latents + sqrt_1m_abar*noise  (scheduler.add_noise, pipeline :177-183)
+ *   ctx            : f32 [2][ctx_len][cross_attention_dim] = [uncond, cond] prompt embeddings
+ *   q,k,v (out)    : compute_dtype [n_images][2][tokens][heads*head_dim]
+ */
+int  dsim_unet_qkv(dsim_unet* h, const float* latents, const float* noise, float sqrt_abar,
+                   float sqrt_1m_abar, const float* ctx, int n_images, void* q, void* k, void* v,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* geometry of the tap for the current cfg: tokens, heads, head_dim */
+int  dsim_unet_tap_shape(const dsim_unet* h, int* tokens, int* heads, int* head_dim);
+
+/* ---- score tail: replaces diffsim/diffsim.py:177-197 (4x F.scaled_dot_product_attention,
+ *      2x F.cosine_similarity or F.mse_loss, mean).  Fused: the O tensors never reach HBM. --
+ *   q,k,v       : dtype [n_feat][B][N][H*D]   (features of n_feat images, B = CFG batch = 2)
+ *   idx_a,idx_b : device int32 [n_pairs]; pair p scores image idx_a[p] against idx_b[p]
+ *   similarity  : 0 cosine, 1 mse
+ *   out_scores  : device f32 [n_pairs]
+ */
+size_t dsim_pair_score_workspace_bytes(int n_pairs, int B, int H, int N, int D);
+int    dsim_pair_score(const void* q, const void* k, const void* v, const int32_t* idx_a,
+                       const int32_t* idx_b, int n_pairs, int B, int H, int N, int D, int dtype,
+                       int similarity, float* out_scores, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* ---- single-operator entry points (kernel-level parity tests and micro-benchmarks) -----
+ * x: dtype [M][K] (or NHWC image for the conv forms); w: diffusers-layout f32 weight.      */
+int dsim_op_linear(const void* x, const float* w /*[N][K]*/, const float* bias /*[N] or NULL*/,
+                   const void* residual /*[M][N] or NULL*/, void* out /*[M][N]*/, int M, int N,
+                   int K, int dtype, int geglu /* w is [2*N][K], out = h*gelu(g) */, void* stream);
+int dsim_op_conv3x3(const void* x /*[B][H][W][Cin]*/, const float* w /*[Cout][Cin][3][3]*/,
+                    const float* bias, const void* residual, void* out, int B, int H, int W,
+                    int Cin, int Cout, int stride, int upsample, int dtype, void* stream);
+int dsim_op_groupnorm(const void* x0, int C0, const void* x1, int C1, const float* gamma,
+                      const float* beta, void* out, int B, int HW, int groups, float eps,
+                      int silu, int dtype, void* stream);
+int dsim_op_layernorm(const void* x, const float* gamma, const float* beta, void* out, int M,
+                      int C, float eps, int dtype, void* stream);
+/* q: [B][Nq][ldq] at column offset h*D; k,v: [Bkv][Nk][ldk]; batch b reads kv batch b % Bkv */
+int dsim_op_attention(const void* q, int ldq, const void* k, const void* v, int ldk, void* out,
+                      int ldo, int B, int Bkv, int H, int Nq, int Nk, int D, int dtype,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFSIM_AMD_H */

@@ -80,7 +80,7 @@ SD15 = UNetConfig()
 # small stand-in with the same topology (4 levels, 3 attention-bearing down/up blocks,
 # straddling concat groups, 8x8 -> 1x1 ... kept >= 2x2 at the bottom) for fast tests
 TINY = UNetConfig(block_out_channels=(64, 128, 256, 256), num_attention_heads=4,
-                  cross_attention_dim=96, sample_size=16, ctx_len=13)
+                  cross_attention_dim=128, sample_size=16, ctx_len=13)
 
 
 # ----------------------------------------------------------------------------------------------

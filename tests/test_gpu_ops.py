@@ -1,0 +1,193 @@
+"""Kernel-level parity: every HIP operator, called through the C ABI, against the same op in
+plain torch fp32 on the CPU.  fp32 mode must agree to ~1e-5 (exact-f32 MFMA, different summation
+order); bf16 mode is compared on bf16-rounded inputs with a bf16-sized tolerance."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _tol(dtype):
+    return (2e-5, 2e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+
+
+def _dev(t, dtype=None):
+    t = t.cuda()
+    return t.to(dtype).contiguous() if dtype is not None else t.contiguous()
+
+
+def _q(t, dtype):
+    """round-trip through the compute dtype so the CPU reference sees the same operand values"""
+    return t.to(dtype).float()
+
+
+def _close(got, want, dtype, scale=None):
+    rt, at = _tol(dtype)
+    got = got.float().cpu()
+    s = float(want.abs().max()) if scale is None else scale
+    err = (got - want).abs().max().item()
+    assert err <= at * max(s, 1e-6) + 1e-7, f"max err {err:.3e} vs scale {s:.3e}"
+    assert torch.isfinite(got).all()
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from diffsim_amd import engine
+    return engine
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (256, 1280, 2560), (154, 640, 768), (64, 64, 128),
+                                   (1000, 1920, 640), (4096, 160, 64)])
+def test_linear(eng, dtype, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    want = F.linear(_q(x, dtype), _q(w, dtype), b)
+    got = eng.op_linear(_dev(x, dtype), _dev(w), _dev(b))
+    _close(got, want, dtype)
+    want2 = want - b + _q(r, dtype)
+    got2 = eng.op_linear(_dev(x, dtype), _dev(w), None, _dev(r, dtype))
+    _close(got2, want2, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C", [(256, 320), (130, 64), (512, 1280)])
+def test_linear_geglu(eng, dtype, M, C):
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g)
+    w = torch.randn(8 * C, C, generator=g) / math.sqrt(C)
+    b = torch.randn(8 * C, generator=g)
+    hg = F.linear(_q(x, dtype), _q(w, dtype), b)
+    hh, gg = hg.chunk(2, dim=-1)
+    want = hh * F.gelu(gg)
+    got = eng.op_linear(_dev(x, dtype), _dev(w), _dev(b), None, geglu=True)
+    assert got.shape == (M, 4 * C)
+    _close(got, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [
+    (2, 16, 16, 64, 128, 1, False), (3, 8, 8, 320, 320, 1, False), (2, 16, 16, 128, 128, 2, False),
+    (2, 8, 8, 128, 64, 1, True), (1, 5, 7, 64, 160, 1, False), (2, 32, 32, 320, 320, 1, False),
+    (2, 8, 8, 1920, 1280, 1, False), (2, 6, 6, 64, 64, 2, False)])
+def test_conv3x3(eng, dtype, B, H, W, Cin, Cout, stride, ups):
+    g = torch.Generator().manual_seed(B * 1000 + H + Cin + Cout + stride)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g)
+    xin = _q(x, dtype)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    want = F.conv2d(xin, _q(w, dtype), b, stride=stride, padding=1)          # NCHW
+    r = torch.randn(want.shape, generator=g)
+    got = eng.op_conv3x3(_dev(x.permute(0, 2, 3, 1), dtype), _dev(w), _dev(b), None, stride, ups)
+    _close(got.float().cpu().permute(0, 3, 1, 2), want, dtype)
+    got2 = eng.op_conv3x3(_dev(x.permute(0, 2, 3, 1), dtype), _dev(w), _dev(b), _dev(r.permute(0, 2, 3, 1), dtype),
+                          stride, ups)
+    _close(got2.float().cpu().permute(0, 3, 1, 2), want + _q(r, dtype), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,HW,C0,C1,silu,eps", [
+    (2, 256, 320, 0, True, 1e-5), (3, 64, 1280, 640, True, 1e-5), (2, 4096, 320, 0, False, 1e-6),
+    (2, 16, 256, 128, True, 1e-5), (1, 1, 1280, 1280, True, 1e-5), (2, 1024, 64, 0, True, 1e-5)])
+def test_groupnorm(eng, dtype, B, HW, C0, C1, silu, eps):
+    g = torch.Generator().manual_seed(HW + C0 + C1)
+    C = C0 + C1
+    x = torch.randn(B, HW, C, generator=g) * 2.0 + 0.7
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    xq = _q(x, dtype)
+    want = F.group_norm(xq.permute(0, 2, 1), 32, gamma, beta, eps)
+    if silu:
+        want = F.silu(want)
+    want = want.permute(0, 2, 1)
+    x0 = _dev(x[:, :, :C0], dtype)
+    x1 = _dev(x[:, :, C0:], dtype) if C1 else None
+    got = eng.op_groupnorm(x0, x1, _dev(gamma), _dev(beta), 32, eps, silu)
+    _close(got, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C", [(257, 320), (64, 1280), (100, 64), (33, 640)])
+def test_layernorm(eng, dtype, M, C):
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g) * 3 + 1
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    want = F.layer_norm(_q(x, dtype), (C,), gamma, beta, 1e-5)
+    got = eng.op_layernorm(_dev(x, dtype), _dev(gamma), _dev(beta))
+    _close(got, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Bkv,H,Nq,Nk,D", [
+    (2, 2, 8, 256, 256, 160), (2, 2, 8, 1024, 1024, 80), (2, 2, 8, 4096, 4096, 40), (4, 2, 8, 256, 77, 160),
+    (2, 2, 4, 64, 64, 16), (2, 2, 4, 16, 13, 64), (3, 3, 2, 100, 70, 32), (2, 2, 8, 64, 64, 160), (2, 1, 16, 256, 256, 72)])
+def test_attention(eng, dtype, B, Bkv, H, Nq, Nk, D):
+    g = torch.Generator().manual_seed(Nq + Nk + D)
+    q = torch.randn(B, Nq, H * D, generator=g) * 1.3
+    k = torch.randn(Bkv, Nk, H * D, generator=g) * 1.3
+    v = torch.randn(Bkv, Nk, H * D, generator=g)
+    qq, kq, vq = _q(q, dtype), _q(k, dtype), _q(v, dtype)
+    idx = torch.arange(B) % Bkv
+    want = F.scaled_dot_product_attention(qq.view(B, Nq, H, D).transpose(1, 2),
+                                          kq[idx].view(B, Nk, H, D).transpose(1, 2),
+                                          vq[idx].view(B, Nk, H, D).transpose(1, 2))
+    want = want.transpose(1, 2).reshape(B, Nq, H * D)
+    got = eng.op_attention(_dev(q, dtype), _dev(k, dtype), _dev(v, dtype), H)
+    _close(got, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pair_score_against_golden_tail(eng, dtype, golden_dir):
+    """Seeded q/k/v sets whose scores were produced by the REFERENCE's DiffSim.diffsim tail
+    (tests/golden/g4_tail.npz): cosine and mse, several shapes, A == B."""
+    import os
+    g4 = np.load(os.path.join(golden_dir, "g4_tail.npz"))
+    for i in range(10):
+        shp = tuple(int(x) for x in g4[f"shape_{i}"])
+        gen = torch.Generator("cpu").manual_seed(int(g4[f"seed_{i}"][0]))
+        sets = [[torch.randn(shp, generator=gen) * (1.5 if j == 0 else 1.0) for j in range(3)] for _ in range(2)]
+        mixw = 0.3 + 0.07 * i
+        sets[1] = [mixw * a + (1 - mixw) * b for a, b in zip(sets[0], sets[1])]
+        if i == 8:
+            sets[1] = [t.clone() for t in sets[0]]
+        Bc, H, N, D = shp
+        # (B,H,N,D) -> engine layout [img][B][N][H*D]
+        feats = [torch.stack([s[j].transpose(1, 2).reshape(Bc, N, H * D) for s in sets]) for j in range(3)]
+        q, k, v = (_dev(f, dtype) for f in feats)
+        ia = torch.tensor([0], dtype=torch.int32).cuda()
+        ib = torch.tensor([1], dtype=torch.int32).cuda()
+        for sim in ("cosine", "mse"):
+            got = eng.pair_score(q, k, v, ia, ib, H, sim).cpu()
+            want = float(g4[f"score_{i}_{sim}"][0])
+            tol = 1e-4 if dtype == torch.float32 else 3e-2
+            assert abs(float(got[0]) - want) <= tol * max(abs(want), 1e-2), (i, sim, float(got[0]), want)
+
+
+def test_pair_score_batched_indices_and_determinism(eng):
+    g = torch.Generator().manual_seed(5)
+    nf, B, H, N, D = 5, 2, 8, 256, 160
+    q, k, v = (torch.randn(nf, B, N, H * D, generator=g).cuda() for _ in range(3))
+    ia = torch.tensor([0, 0, 3, 4, 2], dtype=torch.int32).cuda()
+    ib = torch.tensor([1, 2, 3, 0, 1], dtype=torch.int32).cuda()
+    s1 = eng.pair_score(q, k, v, ia, ib, H, "cosine")
+    s2 = eng.pair_score(q, k, v, ia, ib, H, "cosine")
+    assert torch.equal(s1, s2)                       # fixed-order reduction: bit-reproducible
+    assert abs(float(s1[2]) - 1.0) < 1e-5            # image vs itself with identical features
+    for p in range(5):                               # batch-of-N == N singles, bit for bit
+        sp = eng.pair_score(q, k, v, ia[p:p + 1].clone(), ib[p:p + 1].clone(), H, "cosine")
+        assert torch.equal(sp[0], s1[p])
+    # linearity-style property: swapping roles leaves the symmetric score unchanged
+    s3 = eng.pair_score(q, k, v, ib, ia, H, "cosine")
+    assert torch.allclose(s1, s3, atol=1e-6)

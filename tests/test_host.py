@@ -1,0 +1,110 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol the header declares, host
+logic (image preprocessing, scheduler table, generator order, flag handling) matches the golden
+fixtures captured from the reference.  No compute calls -- there is no GPU here."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from diffsim_amd import _lib, build
+    build.build()
+    return _lib.lib()
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    from diffsim_amd import _lib
+    header = open(os.path.join(ROOT, "include", "diffsim_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(dsim_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.dsim_version() == 1
+    assert lib.dsim_strerror(0) == b"ok"
+    assert b"workspace" in lib.dsim_strerror(-3)
+
+
+def test_engine_fails_loudly_without_gpu():
+    from diffsim_amd import _lib, config as C, synth as S
+    from diffsim_amd.engine import UNetEngine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.DsimError):
+        UNetEngine(C.TINY, {}, torch.float32)
+
+
+def test_g1_process_image_matches_reference():
+    from diffsim_amd.image import load_image, process_image
+    g = np.load(os.path.join(G, "g1_process_image.npz"))
+    for name in "abcd":
+        for size in (64, 128):
+            out = process_image(load_image(os.path.join(G, f"g1_img_{name}.png")), size)
+            assert out.shape == (1, 3, size, size) and out.dtype == torch.float32
+            assert np.array_equal(out.numpy(), g[f"{name}_{size}"])          # bit-exact
+            assert float(out.min()) >= -1.0 and float(out.max()) <= 1.0
+
+
+def test_g2_generator_order():
+    from diffsim_amd.diffsim import get_generator
+    g2 = json.load(open(os.path.join(G, "g2_generator.json")))
+    gen = get_generator(g2["seed"], "cpu")
+    for first in g2["first8"]:
+        d = torch.randn(tuple(g2["shape"]), generator=gen)
+        assert d.flatten()[:8].tolist() == first
+    gens = get_generator([1, 2], "cpu")
+    assert isinstance(gens, list) and len(gens) == 2
+    assert get_generator(None) is None
+
+
+def test_g7_scheduler_table():
+    from diffsim_amd import scheduler as sch
+    g = json.load(open(os.path.join(G, "g7_sched.json")))
+    ts = sch.pndm_timesteps()
+    assert len(ts) == g["pndm_len"] and ts[:4].tolist() == g["pndm_head"] and ts[-3:].tolist() == g["pndm_tail"]
+    for i, t in g["pndm_idx"].items():
+        assert sch.timestep_from_index(int(i)) == t
+    sa, sb = sch.noise_coefficients(401)
+    assert abs(sa - g["sqrt_abar_401"]) < 1e-7 and abs(sb - g["sqrt_1m_abar_401"]) < 1e-7
+    with pytest.raises(IndexError):
+        sch.timestep_from_index(0)
+    with pytest.raises(IndexError):
+        sch.timestep_from_index(1001)
+
+
+def test_target_layer_coercion():
+    from diffsim_amd.diffsim import _norm_layer
+    assert _norm_layer([5]) == 0          # diffsim/diffsim.py:99-100
+    assert _norm_layer([0]) == 0
+    assert _norm_layer(2) == 2
+    with pytest.raises(TypeError):
+        _norm_layer([1, 1])
+
+
+def test_arg_parse_flags():
+    from diffsim_amd.cli import arg_parse
+    a = arg_parse(["--image_path", "x", "--target_block", "up_blocks", "--target_layer", "0", "--target_step", "600",
+                   "--similarity", "cosine", "--metric", "diffsim", "--seed", "2334"])
+    assert a.target_layer == [0] and a.target_step == 600 and a.image_size == 512
+    d = arg_parse([])
+    assert d.similarity == "mse" and d.seed == 2333 and d.prompt == "High quality image"
+
+
+def test_synthetic_inputs_are_deterministic():
+    from diffsim_amd import config as C, synth as S
+    a1, b1 = S.make_pair_latents(C.TINY, 7)
+    a2, b2 = S.make_pair_latents(C.TINY, 7)
+    assert torch.equal(a1, a2) and torch.equal(b1, b2) and not torch.equal(a1, b1)
+    sd1 = S.make_state_dict(C.TINY, 0, keys=["conv_in.weight", "mid_block.resnets.0.norm1.weight"])
+    sd2 = S.make_state_dict(C.TINY, 0)
+    for k in sd1:
+        assert torch.equal(sd1[k], sd2[k])

@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""DiffSim scoring throughput on MI355X: image-pairs/sec, SD1.5 graph, 512 px (64x64 latents),
+tap unet.up_blocks[1].attentions[2].transformer_blocks[0].attn1 (--target_block up_blocks
+--target_layer 0), --target_step 600 (t = 401), cosine.  BASELINE.json config[1].
+
+A "step" = one pass of the hot path (noising + CFG duplication + U-Net-to-tap + q/k/v + fused
+4xSDPA/cosine tail) over one batch of synthetic latent pairs already resident in HBM.
+Weights are seeded random tensors of the real SD1.5 architecture (no checkpoint offline).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0) with the throughput, the roofline of the dominant kernel measured
+live with HIP events on the launch stream, and the CPU oracle timed on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from diffsim_amd import config as C          # noqa: E402
+from diffsim_amd import scheduler as sched   # noqa: E402
+from diffsim_amd import synth as S           # noqa: E402
+
+GFLOP_PER_PAIR = 1580.4          # 4 x 197.2146 GMAC x 2 + 2.684 (tail)
+PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+TAP_KEYS_EXCLUDE = ("up_blocks.2", "up_blocks.3", "conv_norm_out", "conv_out")
+
+# kernel family (dsim_unet_profile_get) -> symbol rocprofv3 --kernel-trace prints
+def rocprof_name(fam: str) -> str:
+    p = fam.split("_")
+    if p[0] == "gemm":
+        t = "__bf16" if p[1] == "bf16" else "float"
+        bm, bn = p[2].split("x")
+        mode = "1" if p[3] == "conv3" else "0"
+        geglu = "true" if fam.endswith("_geglu") else "false"
+        return f"gemm_kernel<{t}, {bm}, {bn}, {mode}, {geglu}>"
+    return fam
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
+    (profiles/rNN_pmc_hbm.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    command, gfx950 FETCH_SIZE x2 correction applied).  PMC cannot be read from inside a normal
+    run, so this is the committed measurement, or None when no summary matches the kernel."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if kernel in d:
+            return d[kernel]["hbm_bytes_per_launch"]
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch-pairs", type=int, default=16, help="pairs per step per GPU")
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the DiffSim engine has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from diffsim_amd.diffsim import DiffSim
+    from diffsim_amd.engine import pair_score
+
+    cfg = C.SD15
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    keys = [k for k in C.unet_param_shapes(cfg) if not k.startswith(TAP_KEYS_EXCLUDE)]
+    sd = S.make_state_dict(cfg, seed=0, keys=keys)
+    ds = DiffSim(torch_dtype=dtype, device=str(dev), unet_config=cfg, state_dict=sd)
+    eng = ds.engine("up_blocks", 0)
+    t = sched.timestep_from_index(600)
+    eng.set_timestep(t)
+    sa, sb = sched.noise_coefficients(t)
+
+    # ---- one batch of synthetic pairs for this rank, resident in HBM ---------------------------
+    bp = a.batch_pairs
+    lats = [S.make_pair_latents(cfg, rank * bp + i) for i in range(bp)]
+    noise = S.draw_pair_noise(2334, lats[0][0].shape)          # reference draw order; [2],[3] = noise A,B
+    lat = torch.cat([torch.cat(p) for p in lats]).to(dev)       # [2*bp] = A0,B0,A1,B1,...
+    nz = torch.cat([noise[2], noise[3]] * bp).to(dev)
+    ctx = S.make_context(cfg).to(dev)
+    ia = torch.arange(0, 2 * bp, 2, dtype=torch.int32, device=dev)
+    ib = ia + 1
+    shape = (2 * bp, 2, eng.tokens, eng.heads * eng.head_dim)
+    qkv = tuple(torch.empty(shape, dtype=dtype, device=dev) for _ in range(3))
+
+    def step():
+        q, k, v = eng.qkv(lat, nz, sa, sb, ctx, out=qkv)
+        return pair_score(q, k, v, ia, ib, eng.heads, "cosine")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        scores = step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        scores = step()
+    if world > 1:                          # the only collective: gather of the scalar scores
+        allscores = [torch.empty_like(scores) for _ in range(world)]
+        dist.all_gather(allscores, scores)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    pairs_per_s = world * a.steps * bp / el
+
+    out = {
+        "metric": "image-pairs/sec at 512px, SD1.5 up_blocks[0] t=600",
+        "value": round(pairs_per_s, 3), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * el / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "DiffSim SD1.5, synthetic 512px pairs (latents-in), up_blocks[0] t=600 (t=401), cosine",
+                   "pairs_per_step_per_gpu": bp, "gflop_per_pair": GFLOP_PER_PAIR, "parallelism": f"pairs sharded x{world}"},
+        "whole_path_tflops_per_gpu": round(pairs_per_s / world * GFLOP_PER_PAIR / 1e3, 2),
+        "score_sample": [round(float(x), 6) for x in scores[:4].float().cpu()],
+    }
+
+    if rank == 0:
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        if not a.no_profile:
+            # ---- roofline of the dominant kernel: HIP events around every launch of one more step
+            eng.profile(True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            q, k, v = eng.qkv(lat, nz, sa, sb, ctx, out=qkv)
+            e0.record()
+            pair_score(q, k, v, ia, ib, eng.heads, "cosine")
+            e1.record()
+            recs = eng.profile_records()
+            eng.profile(False)
+            fam = {}
+            for name, fl, by, ms in recs:
+                f = fam.setdefault(name, [0, 0.0, 0.0, 0.0])
+                f[0] += 1; f[1] += fl; f[2] += by; f[3] += ms
+            tail_ms = e0.elapsed_time(e1)
+            dom = max(fam, key=lambda n: fam[n][3])
+            n, fl, by, ms = fam[dom]
+            ach = fl / (ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": pmc_traffic(rocprof_name(dom)),
+                               "kernel": rocprof_name(dom),
+                               "launches_per_step": n, "avg_launch_ms": round(ms / n, 4),
+                               "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2)}
+            out["kernel_breakdown_ms_per_step"] = {
+                k_: {"n": v_[0], "ms": round(v_[3], 3),
+                     **({"tflops": round(v_[1] / (v_[3] * 1e-3) / 1e12, 1)} if v_[1] else
+                        {"gbps": round(v_[2] / (v_[3] * 1e-3) / 1e9, 1)})}
+                for k_, v_ in sorted(fam.items(), key=lambda kv: -kv[1][3])}
+            out["kernel_breakdown_ms_per_step"]["pair_tail"] = {
+                "n": 2, "ms": round(tail_ms, 3), "tflops": round(bp * 2.684e9 / (tail_ms * 1e-3) / 1e12, 1)}
+        if world == 1 and not a.no_cpu_baseline:
+            # ---- CPU baseline: the oracle (fp32 torch CPU restatement) on the host cores, 1 pair,
+            # same truncated-at-the-tap schedule; also the parity check of pair 0
+            from oracle import cpu_ref as R
+            full = dict(sd)
+            for k_, shp in C.unet_param_shapes(cfg).items():
+                if k_ not in full:
+                    full[k_] = torch.zeros(shp)
+            unet = R.build_unet(R.SD15, full)
+            zA, zB = lats[0]
+            tc = time.perf_counter()
+            so = R.diffsim_latents(unet, zA, zB, noise[2], noise[3], S.make_context(cfg), 600, "up_blocks", 0, "cosine")
+            cpu_s = time.perf_counter() - tc
+            out["cpu_baseline"] = {"value": round(1.0 / cpu_s, 5), "unit": "pairs/s", "cores": torch.get_num_threads(),
+                                   "kind": "port", "sample": "1 pair (pair 0 of the batch), fp32 torch CPU oracle, "
+                                   "U-Net truncated at the tap, host cpu_count=%d" % os.cpu_count()}
+            out["parity_pair0"] = {"gpu": float(scores[0]), "cpu_oracle": float(so),
+                                   "abs_err": abs(float(scores[0]) - float(so))}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch-ROCm owns the device memory and streams this library works on, and its wheel bundles its
+# own HIP runtime.  Import it BEFORE dlopen()ing libdiffsim_amd.so so the library's libamdhip64
+# dependency binds to the runtime torch already loaded; loaded the other way round the process
+# ends up with two HIP runtimes and the second one sees no device.
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdiffsim_amd.so")
 
@@ -45,6 +51,10 @@ SYMBOLS = {
     "dsim_unet_workspace_bytes": (_sz, [_vp, _i]),
     "dsim_unet_qkv": (_i, [_vp, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dsim_unet_tap_shape": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "dsim_unet_profile": (_i, [_vp, _i]),
+    "dsim_unet_profile_count": (_i, [_vp]),
+    "dsim_unet_profile_get": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double)]),
     "dsim_pair_score_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "dsim_pair_score": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "dsim_op_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

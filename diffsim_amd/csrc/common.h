@@ -53,6 +53,7 @@ struct GemmArgs {
     const void* zero_page = nullptr;            // >= 16 zero bytes (padding source)
 };
 int launch_gemm(const GemmArgs& a, int dtype, hipStream_t s);
+void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn);   // which template instantiation launch_gemm picks
 
 // weight repack kernels -- pack.hip  (src f32/bf16/f16 diffusers layout -> packed compute dtype)
 int pack_linear(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int K,

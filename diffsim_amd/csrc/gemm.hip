@@ -16,6 +16,16 @@
 #include "common.h"
 
 namespace dsim {
+
+// tile choice: 160-wide tiles when N allows (every SD channel count is a multiple of 160),
+// 256-row tiles once they still give >= one workgroup per CU.
+void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn) {
+    const bool n160 = (a.N % 160 == 0) && a.epi != EPI_GEGLU;
+    *bn = n160 ? 160 : 128;
+    const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + *bn - 1) / *bn);
+    *bm = tiles256 >= 256 ? 256 : 128;
+}
+
 namespace {
 
 template <typename T> struct Traits;
@@ -260,27 +270,28 @@ int launch_one(const GemmArgs& a, hipStream_t s) {
     return DSIM_OK;
 }
 
-template <typename T>
-int launch_typed(const GemmArgs& a, hipStream_t s) {
-    constexpr int BK = Traits<T>::BK;
+int check_args(const GemmArgs& a, int BK) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % BK) return DSIM_ERR_INVALID;
     if (a.mode == GEMM_CONV3) {
         if (a.C0 % BK || a.K != 9 * a.C0 || a.A1) return DSIM_ERR_INVALID;
     } else {
         if (a.C0 % BK || (a.A1 && a.C1 % BK) || a.K != a.C0 + (a.A1 ? a.C1 : 0)) return DSIM_ERR_INVALID;
     }
+    if (a.epi == EPI_GEGLU && (a.mode != GEMM_LINEAR || a.N % 64)) return DSIM_ERR_INVALID;
     if (!a.zero_page) return DSIM_ERR_INVALID;
-    // tile choice: 160-wide tiles when N allows (every SD channel count is a multiple of 160),
-    // 256-row tiles once they still give >= one workgroup per CU.
-    const bool n160 = (a.N % 160 == 0) && a.epi != EPI_GEGLU;
-    const int bn = n160 ? 160 : 128;
-    const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + bn - 1) / bn);
-    const bool big = tiles256 >= 256;
-    if (a.epi == EPI_GEGLU) {
-        if (a.mode != GEMM_LINEAR || a.N % 64) return DSIM_ERR_INVALID;
+    return DSIM_OK;
+}
+
+template <typename T>
+int launch_typed(const GemmArgs& a, hipStream_t s) {
+    const int st = check_args(a, Traits<T>::BK);
+    if (st != DSIM_OK) return st;
+    int bm, bn;
+    gemm_tile_choice(a, &bm, &bn);
+    const bool big = bm == 256, n160 = bn == 160;
+    if (a.epi == EPI_GEGLU)
         return big ? launch_one<T, 256, 128, GEMM_LINEAR, true>(a, s)
                    : launch_one<T, 128, 128, GEMM_LINEAR, true>(a, s);
-    }
     if (a.mode == GEMM_CONV3) {
         if (n160) return big ? launch_one<T, 256, 160, GEMM_CONV3, false>(a, s)
                              : launch_one<T, 128, 160, GEMM_CONV3, false>(a, s);

@@ -47,6 +47,15 @@ struct Arena {
 
 struct Act { void* p = nullptr; int C = 0, H = 0, W = 0; };
 
+// per-launch record of a profiled forward (dsim_unet_profile_*): kernel family, algorithmic work
+// and the HIP-event bracket on the launch stream
+struct ProfRec {
+    std::string name;
+    double flops = 0, bytes = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0.f;
+};
+
 }  // namespace
 
 struct dsim_unet {
@@ -61,6 +70,8 @@ struct dsim_unet {
     float* temb = nullptr;          // [time_embed_dim]
     float* tscratch = nullptr;      // time-embedding scratch
     std::string err_key;
+    bool profiling = false;
+    std::vector<ProfRec> prof;
 
     // ---- device memory owned by the handle ------------------------------------------------
     int dalloc(size_t bytes, void** out) {
@@ -178,10 +189,39 @@ struct Walk {
     const Packed* var = h->find(key);                    \
     if (!var) return DSIM_ERR_MISSING_WEIGHT;
 
+    // ---- optional per-launch HIP-event brackets (profiled forward only) --------------------
+    void pbegin(const std::string& name, double flops, double bytes) {
+        if (!run || !h->profiling) return;
+        ProfRec r;
+        r.name = name; r.flops = flops; r.bytes = bytes;
+        (void)hipEventCreate(&r.e0);
+        (void)hipEventCreate(&r.e1);
+        (void)hipEventRecord(r.e0, s);
+        h->prof.push_back(r);
+    }
+    void pend() {
+        if (!run || !h->profiling) return;
+        (void)hipEventRecord(h->prof.back().e1, s);
+    }
+    const char* dtn() const { return h->dt == DSIM_F32 ? "f32" : "bf16"; }
+
     int gemm(GemmArgs& g) {
         g.zero_page = h->zero_page;
         if (!run) return DSIM_OK;
-        return launch_gemm(g, h->dt, s);
+        if (h->profiling) {
+            int bm, bn;
+            gemm_tile_choice(g, &bm, &bn);
+            const std::string nm = std::string("gemm_") + dtn() + "_" + std::to_string(bm) + "x" + std::to_string(bn) +
+                                   (g.mode == GEMM_CONV3 ? "_conv3" : "_linear") + (g.epi == EPI_GEGLU ? "_geglu" : "");
+            const double e = (double)es();
+            const double outc = g.epi == EPI_GEGLU ? g.N / 2 : g.N;
+            pbegin(nm, 2.0 * g.M * (double)g.N * g.K,
+                   e * ((double)g.M * (g.mode == GEMM_CONV3 ? g.C0 : g.K) + (double)g.N * g.K +
+                        (double)g.M * outc * (g.residual ? 2 : 1)));
+        }
+        const int st = launch_gemm(g, h->dt, s);
+        pend();
+        return st;
     }
     int linear(const void* a0, int c0, const void* a1, int c1, const Packed* w, const Packed* b, const void* residual,
                void* out, int M, int N, int ldo, int epi = -1) {
@@ -210,16 +250,29 @@ struct Walk {
     }
     int gn(const Act& x0, const Act* x1, const Packed* g, const Packed* b, void* out, float eps, int silu) {
         if (!run) return DSIM_OK;
-        return launch_groupnorm(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, (const float*)g->p, (const float*)b->p,
-                                out, B2, x0.H * x0.W, h->cfg.norm_num_groups, eps, silu, h->dt, gn_scratch, s);
+        const double n = (double)B2 * x0.H * x0.W * (x0.C + (x1 ? x1->C : 0));
+        pbegin(std::string("groupnorm_") + dtn(), 0.0, 3.0 * n * es());      // read (stats) + read + write
+        const int st = launch_groupnorm(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, (const float*)g->p,
+                                        (const float*)b->p, out, B2, x0.H * x0.W, h->cfg.norm_num_groups, eps, silu,
+                                        h->dt, gn_scratch, s);
+        pend();
+        return st;
     }
     int ln(const void* x, const Packed* g, const Packed* b, void* out, int M, int C) {
         if (!run) return DSIM_OK;
-        return launch_layernorm(x, (const float*)g->p, (const float*)b->p, out, M, C, 1e-5f, h->dt, s);
+        pbegin(std::string("layernorm_") + dtn(), 0.0, 2.0 * M * (double)C * es());
+        const int st = launch_layernorm(x, (const float*)g->p, (const float*)b->p, out, M, C, 1e-5f, h->dt, s);
+        pend();
+        return st;
     }
     int attn(const AttnArgs& a) {
         if (!run) return DSIM_OK;
-        return launch_attention(a, h->dt, s);
+        pbegin(std::string("attention_") + dtn() + "_d" + std::to_string(a.D),
+               4.0 * a.B * a.H * (double)a.Nq * a.Nk * a.D,
+               (double)es() * a.B * a.H * a.D * (2.0 * a.Nq + 2.0 * a.Nk));
+        const int st = launch_attention(a, h->dt, s);
+        pend();
+        return st;
     }
 
     // ResnetBlock2D; x1 = skip tensor concatenated after x0 on channels
@@ -331,8 +384,13 @@ struct Walk {
         if (run) CK(convert_f32_to(ctx, ctx_t, h->dt, (size_t)2 * L * Dc, s));
         WGET(ciw, "conv_in.weight"); WGET(cib, "conv_in.bias");
         Act x{alloc_act((size_t)B2 * S * S * ch0), ch0, S, S};
-        if (run) CK(prep_conv_in(lat, noise, sa, sb, (const float*)ciw->p, (const float*)cib->p, x.p, h->dt, B2 / 2,
-                                 c.in_channels, S, ch0, s));
+        if (run) {
+            pbegin("prep_conv_in", 2.0 * B2 * S * S * (double)ch0 * 9 * c.in_channels, (double)B2 * S * S * ch0 * es());
+            const int st = prep_conv_in(lat, noise, sa, sb, (const float*)ciw->p, (const float*)cib->p, x.p, h->dt,
+                                        B2 / 2, c.in_channels, S, ch0, s);
+            pend();
+            CK(st);
+        }
         std::vector<Act> skips;
         skips.push_back(x);
         // ---- down path (hacked_modules.py:583-618) ---------------------------------------
@@ -590,6 +648,33 @@ int dsim_unet_qkv(dsim_unet* h, const float* latents, const float* noise, float 
     CK(w.go(latents, noise, sqrt_abar, sqrt_1m_abar, ctx));
     if (ar.overflow) return DSIM_ERR_WORKSPACE;
     return w.tapped ? DSIM_OK : DSIM_ERR_INVALID;
+}
+
+int dsim_unet_profile(dsim_unet* h, int enable) {
+    if (!h) return DSIM_ERR_INVALID;
+    for (auto& r : h->prof) {
+        if (r.e0) (void)hipEventDestroy(r.e0);
+        if (r.e1) (void)hipEventDestroy(r.e1);
+    }
+    h->prof.clear();
+    h->profiling = enable != 0;
+    return DSIM_OK;
+}
+
+int dsim_unet_profile_count(const dsim_unet* h) { return h ? (int)h->prof.size() : 0; }
+
+int dsim_unet_profile_get(dsim_unet* h, int i, char* name, int name_cap, double* flops, double* bytes, double* ms) {
+    if (!h || i < 0 || i >= (int)h->prof.size() || !name || name_cap < 2 || !flops || !bytes || !ms)
+        return DSIM_ERR_INVALID;
+    ProfRec& r = h->prof[i];
+    if (r.e0 && r.e1) {
+        DSIM_HIP_CHECK(hipEventSynchronize(r.e1));
+        DSIM_HIP_CHECK(hipEventElapsedTime(&r.ms, r.e0, r.e1));
+    }
+    strncpy(name, r.name.c_str(), (size_t)name_cap - 1);
+    name[name_cap - 1] = 0;
+    *flops = r.flops; *bytes = r.bytes; *ms = (double)r.ms;
+    return DSIM_OK;
 }
 
 size_t dsim_pair_score_workspace_bytes(int n_pairs, int B, int H, int N, int D) {

@@ -109,6 +109,22 @@ class UNetEngine:
                 _lib.check(self.L.dsim_unet_set_timestep(self._h, int(t), _stream_ptr()), "set_timestep")
             self._t = t
 
+    def profile(self, enable: bool):
+        _lib.check(self.L.dsim_unet_profile(self._h, int(enable)), "profile")
+
+    def profile_records(self):
+        """[(kernel family, algorithmic flops, algorithmic bytes, ms)] of the forwards run since
+        profile(True); synchronises the device first."""
+        torch.cuda.synchronize(self.device)
+        out = []
+        buf = C.create_string_buffer(128)
+        fl, by, ms = C.c_double(), C.c_double(), C.c_double()
+        for i in range(self.L.dsim_unet_profile_count(self._h)):
+            _lib.check(self.L.dsim_unet_profile_get(self._h, i, buf, 128, C.byref(fl), C.byref(by), C.byref(ms)),
+                       "profile_get")
+            out.append((buf.value.decode(), fl.value, by.value, ms.value))
+        return out
+
     def workspace_bytes(self, n_images: int) -> int:
         return int(self.L.dsim_unet_workspace_bytes(self._h, n_images))
 

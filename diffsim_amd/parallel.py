@@ -1,0 +1,60 @@
+"""Multi-GPU sharding of DiffSim scoring: one process per GPU, pairs are the shard unit.
+
+The reference is a single-process, single-GPU, batch-of-one loop (cute_main.py:54-132,
+``export CUDA_VISIBLE_DEVICES=N`` in the *.sh drivers).  Pairs are independent and weights are
+read-only, so the build shards the pair list across ranks with NO data-path collective; the only
+communication is one all_gather of the fp32 scores at the end (RCCL over xGMI with the "nccl"
+backend on GPUs; gloo on CPU in the tests).  4 bytes per pair: latency-bound, not bandwidth-bound.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """Strided shard: rank r owns items r, r+world, ... (balanced to within one item)."""
+    return list(range(rank, n_items, world))
+
+
+def shard_triplets(n_triplets: int, rank: int, world: int) -> List[int]:
+    """Triplets (ref, left, right) are sharded whole so the reference image's cached features are
+    reused inside one rank."""
+    return shard_indices(n_triplets, rank, world)
+
+
+def gather_scores(local_scores: torch.Tensor, n_items: int, rank: int, world: int) -> torch.Tensor:
+    """All-gather the per-rank score vectors of a strided shard back into item order.
+
+    ``local_scores`` holds the scores of ``shard_indices(n_items, rank, world)`` in that order, on
+    the device the process group works with.  Returns a length-``n_items`` fp32 tensor on every rank.
+    """
+    if world == 1:
+        return local_scores.float()
+    per = (n_items + world - 1) // world
+    pad = torch.full((per,), float("nan"), dtype=torch.float32, device=local_scores.device)
+    pad[: local_scores.numel()] = local_scores.float()
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    out = torch.empty(n_items, dtype=torch.float32, device=local_scores.device)
+    for r in range(world):
+        idx = shard_indices(n_items, r, world)
+        out[idx] = bufs[r][: len(idx)]
+    return out
+
+
+def score_pairs_sharded(scorer, latA: torch.Tensor, latB: torch.Tensor, noiseA, noiseB, prompt, rank: int, world: int,
+                        **kw) -> torch.Tensor:
+    """Score pairs (latA[i], latB[i]) with rank r taking i = r (mod world); every rank returns all
+    scores in pair order.  Per-pair results are bit-identical to the single-GPU run because the
+    engine's reductions are fixed-order and batch-invariant."""
+    n = latA.shape[0]
+    idx = shard_indices(n, rank, world)
+    if idx:
+        sel = torch.tensor(idx, dtype=torch.long)
+        local = scorer.score_latent_pairs(latA[sel], latB[sel], noiseA, noiseB, prompt, **kw)
+    else:
+        local = torch.empty(0, dtype=torch.float32, device=scorer.device)
+    return gather_scores(local, n, rank, world)

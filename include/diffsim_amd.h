@@ -107,6 +107,16 @@ int  dsim_unet_qkv(dsim_unet* h, const float* latents, const float* noise, float
                    float sqrt_1m_abar, const float* ctx, int n_images, void* q, void* k, void* v,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* Measurement aid (bench.py's roofline leg): while enabled, dsim_unet_qkv brackets every kernel
+ * launch with a pair of HIP events recorded on the launch stream.  After the caller has
+ * synchronised the stream, dsim_unet_profile_get returns, per launch: the kernel family name
+ * (e.g. "gemm_bf16_256x160_conv3"), its ALGORITHMIC flops and bytes, and the elapsed ms.
+ * dsim_unet_profile(h, enable) clears earlier records.  Not for use inside a timed region. */
+int  dsim_unet_profile(dsim_unet* h, int enable);
+int  dsim_unet_profile_count(const dsim_unet* h);
+int  dsim_unet_profile_get(dsim_unet* h, int i, char* name, int name_cap, double* flops,
+                           double* bytes, double* ms);
+
 /* geometry of the tap for the current cfg: tokens, heads, head_dim */
 int  dsim_unet_tap_shape(const dsim_unet* h, int* tokens, int* heads, int* head_dim);
 

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 output that a gpurun call merged into gpurun_out/ into the small, tracked
+summaries under profiles/ (gpurun_out/ is scratch).
+
+  python profiles/summarize.py r01 gpurun_out/prof_r1_trace gpurun_out/prof_r1_fetch gpurun_out/prof_r1_write
+
+Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, one row per kernel) and
+profiles/<tag>_pmc_hbm.json (per kernel: launches, FETCH_SIZE and WRITE_SIZE per launch in KB as the
+counters report them, and HBM bytes per launch with the gfx950 correction of
+MI355X_MICROARCH.md section HBM: FETCH_SIZE counts half the bytes of wide coalesced reads -> x2).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def demangle(names):
+    try:
+        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True,
+                             text=True, check=True).stdout.splitlines()
+        return dict(zip(names, out))
+    except Exception:
+        return {n: n for n in names}
+
+
+def short(n):
+    """llvm-cxxfilt of this ROCm does not know the DF16b (__bf16) mangling: prettify by hand."""
+    m = re.match(r"_ZN4dsim12_GLOBAL__N_1\d+([a-z_0-9]+?)I(.*?)EEv", n)
+    if m:
+        args = []
+        for tok in re.findall(r"DF16b|f|Li\d+E|Lb[01]E", m.group(2)):
+            if tok == "DF16b":
+                args.append("__bf16")
+            elif tok == "f":
+                args.append("float")
+            elif tok.startswith("Li"):
+                args.append(tok[2:-1])
+            else:
+                args.append("true" if tok[2] == "1" else "false")
+        return f"{m.group(1)}<{', '.join(args)}>"
+    n = n.replace("dsim::(anonymous namespace)::", "").replace("void ", "")
+    return re.sub(r"\(.*$", "", n)
+
+
+def main():
+    tag, trace, fetch, write = sys.argv[1:5]
+    stats = glob.glob(os.path.join(trace, "**", "*kernel_stats.csv"), recursive=True)[0]
+    rows = list(csv.DictReader(open(stats)))
+    dm = demangle([r["Name"] for r in rows])
+    with open(os.path.join(HERE, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ns", "average_ns", "percent", "min_ns", "max_ns"])
+        for r in rows:
+            w.writerow([short(dm[r["Name"]]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                        r["MinNs"], r["MaxNs"]])
+    pmc = collections.defaultdict(lambda: {"launches": 0, "FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0})
+    for d, key in ((fetch, "FETCH_SIZE_KB"), (write, "WRITE_SIZE_KB")):
+        f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+        rr = list(csv.DictReader(open(f)))
+        dm2 = demangle(sorted({r["Kernel_Name"] for r in rr}))
+        for r in rr:
+            e = pmc[short(dm2[r["Kernel_Name"]])]
+            e[key] += float(r["Counter_Value"])
+            if key == "FETCH_SIZE_KB":
+                e["launches"] += 1
+    out = {}
+    for k, e in pmc.items():
+        n = max(e["launches"], 1)
+        fk, wk = e["FETCH_SIZE_KB"] / n, e["WRITE_SIZE_KB"] / n
+        out[k] = {"launches": e["launches"], "fetch_size_kb_per_launch": round(fk, 1),
+                  "write_size_kb_per_launch": round(wk, 1),
+                  "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024)}
+    json.dump(out, open(os.path.join(HERE, f"{tag}_pmc_hbm.json"), "w"), indent=1, sort_keys=True)
+    print("wrote", tag)
+
+
+if __name__ == "__main__":
+    main()

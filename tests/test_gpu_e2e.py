@@ -160,11 +160,12 @@ def test_sd15_channels_small_latent_fp32():
         assert abs(sb - so) <= ABS_BF16, (sb, so)
 
 
-def test_errors_are_loud(tiny_env):
+def test_errors_are_loud(tiny_env, golden_dir):
     from diffsim_amd import _lib
     ds = _scorer(C.TINY, tiny_env["sd"], torch.float32)
+    img = os.path.join(golden_dir, "g1_img_c.png")
     with pytest.raises(RuntimeError):
-        ds.diffsim("a.png", "b.png", 128, "p", "up_blocks", [0], 600)          # no VAE plugged in
+        ds.diffsim(img, img, 128, "p", "up_blocks", [0], 600)                   # no VAE plugged in
     with pytest.raises(IndexError):
         zA, zB = S.make_pair_latents(C.TINY, 0)
         ds.diffsim_latents(zA, zB, zA, zB, tiny_env["ctx"], target_step=0)      # idx 0 -> t=1000

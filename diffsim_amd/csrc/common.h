@@ -53,6 +53,7 @@ struct GemmArgs {
     const void* zero_page = nullptr;            // >= 16 zero bytes (padding source)
 };
 int launch_gemm(const GemmArgs& a, int dtype, hipStream_t s);
+extern int g_force_bm;     // 0 = heuristic; 128/256 force the row tile (micro-benchmark A/B only)
 void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn);   // which template instantiation launch_gemm picks
 
 // weight repack kernels -- pack.hip  (src f32/bf16/f16 diffusers layout -> packed compute dtype)

@@ -19,11 +19,15 @@ namespace dsim {
 
 // tile choice: 160-wide tiles when N allows (every SD channel count is a multiple of 160),
 // 256-row tiles once they still give >= one workgroup per CU.
+int g_force_bm = 0;
 void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn) {
     const bool n160 = (a.N % 160 == 0) && a.epi != EPI_GEGLU;
     *bn = n160 ? 160 : 128;
-    const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + *bn - 1) / *bn);
-    *bm = tiles256 >= 256 ? 256 : 128;
+    // 128-row tiles: two workgroups per CU (<= 74 KB LDS each), so one workgroup's epilogue and
+    // tile-boundary bubbles overlap the other's loads.  Measured faster than 256-row tiles at one
+    // workgroup per CU on every SD1.5 shape with this 2-stage pipeline (tools/kbench A/B).
+    *bm = 128;
+    if (g_force_bm == 128 || g_force_bm == 256) *bm = g_force_bm;     // development override (kbench A/B)
 }
 
 namespace {
@@ -68,9 +72,32 @@ __device__ __forceinline__ void mma(const FragF32& a, const FragF32& b, f32x16& 
 template <typename T> struct FragOf { typedef bf16x8 type; };
 template <> struct FragOf<float> { typedef FragF32 type; };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. f32 rounding level): one v_rcp, one
+// v_exp and 7 FMAs instead of libm erff's ~30-instruction branchy polynomial -- the GEGLU epilogue
+// evaluates it 64x per thread per tile and was VALU-bound on it.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    pl *= t;
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+    const float r = fmaf(-pl, e, 1.0f);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+
+// LDS: two staging buffers for the K loop; the epilogue's four wave-private transpose slabs reuse them
+template <typename T, int BM, int BN, bool GEGLU>
+constexpr int gemm_lds_bytes() {
+    const int stage2 = 2 * (BM + BN) * 128;
+    const int epi = 4 * 32 * ((GEGLU ? BN / 2 : BN) * (int)sizeof(T) + 16);
+    return stage2 > epi ? stage2 : epi;
+}
 
 template <typename T, int BM, int BN, int MODE, bool GEGLU>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p, const int tilesN) {
@@ -202,53 +229,107 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p, const int t
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) mma(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) mma(b[j], a[i], acc[i][j]);   // D^T: rows = n (registers), cols = m (lane)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
-    // ---- epilogue: column on the lane, 16 rows in registers ---------------------------------
+    // ---- epilogue -------------------------------------------------------------------------
+    // The accumulators hold D^T: lane = output row m (lane&31), registers = 16 output columns
+    // n = 8*(r>>2) + 4*half + (r&3) of a 32-wide block.  Each wave transposes its 32-row slab
+    // through a private LDS region (the K loop's last barrier freed the staging buffers), then
+    // streams it out row-contiguously: 16-byte coalesced residual loads and stores.
+    constexpr int ES = sizeof(T);
+    constexpr int OUTW = GEGLU ? BN / 2 : BN;
+    constexpr int RSO = OUTW * ES + 16;                 // staging row stride (bytes)
+    constexpr int CPR = OUTW * ES / 16;                 // 16-byte chunks per output row
+    char* const wst = smem + wave * (32 * RSO);
     T* const out = (T*)p.out;
     const T* const res = (const T*)p.residual;
-    const int mw = m0 + wave * (BM / 4) + 4 * half;
-    if (!GEGLU) {
+    const int nout0 = GEGLU ? (n0 >> 1) : n0;
+    const int Nout = GEGLU ? (p.N >> 1) : p.N;
+    const int l31 = lane & 31;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + j * 32 + (lane & 31);
-            if (n >= p.N) continue;
-            const float bv = p.bias ? p.bias[n] : 0.0f;
+    for (int i = 0; i < TM; ++i) {
+        // register phase
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; j += (GEGLU ? 2 : 1)) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (m < p.M) {
-                        float v = acc[i][j][r] + bv;
-                        const size_t o = (size_t)m * p.ldo + n;
-                        if (p.epi == EPI_RESIDUAL) v += to_f32(res[o]);
-                        out[o] = (T)v;
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+                if (GEGLU) {
+                    // packed weight rows alternate 32-row blocks [h-block, g-block]
+                    const int nh = n0 + j * 32 + 8 * g + 4 * half;
+                    f32x4 bh = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias && nh < p.N) {
+                        bh = *reinterpret_cast<const f32x4*>(p.bias + nh);
+                        bg = *reinterpret_cast<const f32x4*>(p.bias + nh + 32);
                     }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = (acc[i][j][4 * g + e] + bh[e]) * gelu_erf(acc[i][j + 1][4 * g + e] + bg[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                }
+                const int col = (GEGLU ? (j >> 1) : j) * 32 + 8 * g + 4 * half;
+                char* dst = wst + l31 * RSO + col * ES;
+                if constexpr (sizeof(T) == 2) {
+                    bf16x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (bf16)v[e];
+                    *reinterpret_cast<bf16x4*>(dst) = pk;
+                } else {
+                    f32x4 pk = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(dst) = pk;
                 }
             }
         }
-    } else {
-        // packed rows alternate 32-wide blocks: [h-block, g-block]; out column = packed/2
+        // read-back phase (same wave: LDS operations of one wave execute in order)
+        const int mrow0 = m0 + wave * (BM / 4) + i * 32;
+        for (int idx = lane; idx < 32 * CPR; idx += 64) {
+            const int row = idx / CPR, c = idx - row * CPR;
+            const int m = mrow0 + row, ncol = c * VEC;
+            if (m < p.M && nout0 + ncol < Nout) {
+                const size_t o = (size_t)m * p.ldo + nout0 + ncol;
+                float v[VEC];
+                if constexpr (sizeof(T) == 2) {
+                    const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(wst + row * RSO + c * 16);
 #pragma unroll
-        for (int j = 0; j < TN; j += 2) {
-            const int nh = n0 + j * 32 + (lane & 31);
-            if (nh >= p.N) continue;
-            const float bh = p.bias ? p.bias[nh] : 0.0f, bg = p.bias ? p.bias[nh + 32] : 0.0f;
-            const int no = (n0 >> 1) + (j >> 1) * 32 + (lane & 31);
+                    for (int e = 0; e < 8; ++e) v[e] = (float)t8[e];
+                } else {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(wst + row * RSO + c * 16);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+                    for (int e = 0; e < 4; ++e) v[e] = t4[e];
+                }
+                if (!GEGLU && p.bias) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (m < p.M) {
-                        const float hv = acc[i][j][r] + bh, gv = acc[i][j + 1][r] + bg;
-                        out[(size_t)m * p.ldo + no] = (T)(hv * gelu_erf(gv));
+                    for (int e = 0; e < VEC; e += 4) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + nout0 + ncol + e);
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) v[e + f] += b4[f];
                     }
+                }
+                if (p.epi == EPI_RESIDUAL) {
+                    if constexpr (sizeof(T) == 2) {
+                        const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(res + o);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+                    } else {
+                        const f32x4 r4 = *reinterpret_cast<const f32x4*>(res + o);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += r4[e];
+                    }
+                }
+                if constexpr (sizeof(T) == 2) {
+                    bf16x8 o8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o8[e] = (bf16)v[e];
+                    *reinterpret_cast<bf16x8*>(out + o) = o8;
+                } else {
+                    f32x4 o4 = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(out + o) = o4;
                 }
             }
         }
@@ -257,7 +338,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p, const int t
 
 template <typename T, int BM, int BN, int MODE, bool GEGLU>
 int launch_one(const GemmArgs& a, hipStream_t s) {
-    constexpr int LDS = 2 * (BM + BN) * 128;
+    constexpr int LDS = gemm_lds_bytes<T, BM, BN, GEGLU>();
     static bool attr_done = false;   // one handle per device / one host thread per handle
     auto kern = gemm_kernel<T, BM, BN, MODE, GEGLU>;
     if (!attr_done) {

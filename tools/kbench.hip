@@ -1,0 +1,176 @@
+// Kernel micro-benchmark (development aid, not part of the product): times the GEMM / conv /
+// attention / norm kernels on the exact shapes of one SD1.5 step (B2 U-Net batch elements) with HIP
+// events, random bf16 data.  Build: python tools/build_kbench.py ; run on the GPU box:
+//   ./tools/kbench [B2=64] [iters=10] [filter]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../diffsim_amd/csrc/common.h"
+
+using namespace dsim;
+
+#define HC(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void fill_bf16(bf16* p, size_t n, unsigned seed, float scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned x = (unsigned)(i * 2654435761u) ^ seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    p[i] = (bf16)(((float)(x & 0xffff) / 32768.0f - 1.0f) * scale);
+}
+__global__ void fill_f32(float* p, size_t n, unsigned seed, float scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned x = (unsigned)(i * 2654435761u) ^ seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+    p[i] = ((float)(x & 0xffff) / 32768.0f - 1.0f) * scale;
+}
+
+static void* dalloc_bf16(size_t n, unsigned seed, float scale = 1.0f) {
+    void* p;
+    HC(hipMalloc(&p, n * 2 + 256));
+    hipLaunchKernelGGL(fill_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (bf16*)p, n, seed, scale);
+    return p;
+}
+static float* dalloc_f32(size_t n, unsigned seed, float scale = 1.0f) {
+    float* p;
+    HC(hipMalloc((void**)&p, n * 4 + 256));
+    hipLaunchKernelGGL(fill_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, p, n, seed, scale);
+    return p;
+}
+
+struct Timer {
+    hipEvent_t a, b;
+    Timer() { HC(hipEventCreate(&a)); HC(hipEventCreate(&b)); }
+    template <typename F> float run(F f, int iters) {
+        f();
+        HC(hipDeviceSynchronize());
+        HC(hipEventRecord(a, 0));
+        for (int i = 0; i < iters; ++i) f();
+        HC(hipEventRecord(b, 0));
+        HC(hipEventSynchronize(b));
+        float ms;
+        HC(hipEventElapsedTime(&ms, a, b));
+        return ms / iters;
+    }
+};
+
+static const char* g_filter = nullptr;
+static bool want(const std::string& n) { return !g_filter || n.find(g_filter) != std::string::npos; }
+
+static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H, int W, int epi, int iters, Timer& t,
+                       void* zp, int C1 = 0) {
+    if (!want(name)) return;
+    GemmArgs g;
+    const int K = mode == GEMM_CONV3 ? 9 * Cin : Cin + C1;
+    const int outc = epi == EPI_GEGLU ? N / 2 : N;
+    void* A = dalloc_bf16((size_t)M * Cin, 1);
+    void* A1 = C1 ? dalloc_bf16((size_t)M * C1, 5) : nullptr;
+    void* Wt = dalloc_bf16((size_t)N * K, 2, 0.05f);
+    float* bias = dalloc_f32(N, 3);
+    void* res = dalloc_bf16((size_t)M * outc, 4);
+    void* out;
+    HC(hipMalloc(&out, (size_t)M * outc * 2));
+    g.A0 = A; g.C0 = Cin; g.A1 = A1; g.C1 = C1; g.mode = mode; g.Hin = g.Hout = H; g.Win = g.Wout = W; g.M = M; g.N = N; g.K = K;
+    g.W = Wt; g.bias = bias; g.epi = epi; g.residual = epi == EPI_RESIDUAL ? res : nullptr; g.out = out; g.ldo = outc;
+    g.zero_page = zp;
+    int st = DSIM_OK;
+    const double fl = 2.0 * M * (double)N * K;
+    float msv[3];
+    const int forces[3] = {128, 256, 0};
+    for (int v = 0; v < 3; ++v) {
+        g_force_bm = forces[v];
+        msv[v] = t.run([&] { st = launch_gemm(g, DSIM_BF16, 0); }, iters);
+    }
+    int bm, bn;
+    gemm_tile_choice(g, &bm, &bn);
+    printf("%-26s M=%7d N=%5d K=%5d  bm128 %7.3f ms %6.1f TF | bm256 %7.3f ms %6.1f TF | auto %dx%d %7.3f ms %6.1f TF st=%d\n",
+           name, M, N, K, msv[0], fl / msv[0] / 1e9, msv[1], fl / msv[1] / 1e9, bm, bn, msv[2], fl / msv[2] / 1e9, st);
+    HC(hipFree(A)); if (A1) HC(hipFree(A1)); HC(hipFree(Wt)); HC(hipFree(bias)); HC(hipFree(res)); HC(hipFree(out));
+}
+
+static void bench_attn(const char* name, int B, int Bkv, int H, int Nq, int Nk, int D, int iters, Timer& t) {
+    if (!want(name)) return;
+    const int C = H * D;
+    const bool self = Bkv == B && Nq == Nk;
+    void* q = dalloc_bf16((size_t)B * Nq * (self ? 3 * C : C), 1);
+    void* kv = self ? nullptr : dalloc_bf16((size_t)Bkv * Nk * 2 * C, 2);
+    void* out;
+    HC(hipMalloc(&out, (size_t)B * Nq * C * 2));
+    AttnArgs a;
+    if (self) { a.q = q; a.ldq = 3 * C; a.k = (char*)q + C * 2; a.v = (char*)q + 2 * C * 2; a.ldk = 3 * C; }
+    else { a.q = q; a.ldq = C; a.k = kv; a.v = (char*)kv + C * 2; a.ldk = 2 * C; }
+    a.out = out; a.ldo = C; a.B = B; a.Bkv = Bkv; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D;
+    int st = DSIM_OK;
+    const float ms = t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters);
+    const double fl = 4.0 * B * H * (double)Nq * Nk * D;
+    printf("%-28s B=%3d H=%d Nq=%5d Nk=%5d D=%3d        %8.3f ms  %7.1f TF/s  st=%d\n", name, B, H, Nq, Nk, D, ms, fl / ms / 1e9, st);
+    HC(hipFree(q)); if (kv) HC(hipFree(kv)); HC(hipFree(out));
+}
+
+static void bench_gn(const char* name, int B, int HW, int C, int iters, Timer& t) {
+    if (!want(name)) return;
+    void* x = dalloc_bf16((size_t)B * HW * C, 1);
+    float* g = dalloc_f32(C, 2);
+    float* b = dalloc_f32(C, 3);
+    void *out, *sc;
+    HC(hipMalloc(&out, (size_t)B * HW * C * 2));
+    HC(hipMalloc(&sc, groupnorm_scratch_bytes(B, 32)));
+    int st = DSIM_OK;
+    const float ms = t.run([&] { st = launch_groupnorm(x, C, nullptr, 0, g, b, out, B, HW, 32, 1e-5f, 1, DSIM_BF16, sc, 0); }, iters);
+    const double by = 3.0 * B * (double)HW * C * 2;
+    printf("%-28s B=%3d HW=%5d C=%5d                 %8.3f ms  %7.1f GB/s  st=%d\n", name, B, HW, C, ms, by / ms / 1e6, st);
+    const float ms2 = t.run([&] { st = launch_layernorm(x, g, b, out, B * HW, C, 1e-5f, DSIM_BF16, 0); }, iters);
+    printf("%-28s M=%7d C=%5d                        %8.3f ms  %7.1f GB/s  st=%d\n", (std::string(name) + "_ln").c_str(), B * HW, C, ms2,
+           2.0 * B * (double)HW * C * 2 / ms2 / 1e6, st);
+    HC(hipFree(x)); HC(hipFree(g)); HC(hipFree(b)); HC(hipFree(out)); HC(hipFree(sc));
+}
+
+int main(int argc, char** argv) {
+    const int B2 = argc > 1 ? atoi(argv[1]) : 64;
+    const int iters = argc > 2 ? atoi(argv[2]) : 10;
+    g_filter = argc > 3 ? argv[3] : nullptr;
+    void* zp;
+    HC(hipMalloc(&zp, 256));
+    HC(hipMemset(zp, 0, 256));
+    Timer t;
+    const int s64 = B2 * 4096, s32 = B2 * 1024, s16 = B2 * 256, s8 = B2 * 64;
+    // ---- 3x3 convs ----
+    bench_gemm("conv3_64_320_320", GEMM_CONV3, s64, 320, 320, 64, 64, EPI_NONE, iters, t, zp);
+    bench_gemm("conv3_64_320_320_res", GEMM_CONV3, s64, 320, 320, 64, 64, EPI_RESIDUAL, iters, t, zp);
+    bench_gemm("conv3_32_320_640", GEMM_CONV3, s32, 640, 320, 32, 32, EPI_NONE, iters, t, zp);
+    bench_gemm("conv3_32_640_640", GEMM_CONV3, s32, 640, 640, 32, 32, EPI_RESIDUAL, iters, t, zp);
+    bench_gemm("conv3_16_640_1280", GEMM_CONV3, s16, 1280, 640, 16, 16, EPI_NONE, iters, t, zp);
+    bench_gemm("conv3_16_1280_1280", GEMM_CONV3, s16, 1280, 1280, 16, 16, EPI_RESIDUAL, iters, t, zp);
+    bench_gemm("conv3_16_2560_1280", GEMM_CONV3, s16, 1280, 2560, 16, 16, EPI_NONE, iters, t, zp);
+    bench_gemm("conv3_8_1280_1280", GEMM_CONV3, s8, 1280, 1280, 8, 8, EPI_RESIDUAL, iters, t, zp);
+    bench_gemm("conv3_8_2560_1280", GEMM_CONV3, s8, 1280, 2560, 8, 8, EPI_NONE, iters, t, zp);
+    // ---- linears ----
+    bench_gemm("lin_64_320_320_res", GEMM_LINEAR, s64, 320, 320, 0, 0, EPI_RESIDUAL, iters, t, zp);
+    bench_gemm("lin_64_320_960_qkv", GEMM_LINEAR, s64, 960, 320, 0, 0, EPI_NONE, iters, t, zp);
+    bench_gemm("lin_64_320_2560_geglu", GEMM_LINEAR, s64, 2560, 320, 0, 0, EPI_GEGLU, iters, t, zp);
+    bench_gemm("lin_64_1280_320_res", GEMM_LINEAR, s64, 320, 1280, 0, 0, EPI_RESIDUAL, iters, t, zp);
+    bench_gemm("lin_32_640_640_res", GEMM_LINEAR, s32, 640, 640, 0, 0, EPI_RESIDUAL, iters, t, zp);
+    bench_gemm("lin_32_640_1920_qkv", GEMM_LINEAR, s32, 1920, 640, 0, 0, EPI_NONE, iters, t, zp);
+    bench_gemm("lin_32_640_5120_geglu", GEMM_LINEAR, s32, 5120, 640, 0, 0, EPI_GEGLU, iters, t, zp);
+    bench_gemm("lin_32_2560_640_res", GEMM_LINEAR, s32, 640, 2560, 0, 0, EPI_RESIDUAL, iters, t, zp);
+    bench_gemm("lin_16_1280_1280_res", GEMM_LINEAR, s16, 1280, 1280, 0, 0, EPI_RESIDUAL, iters, t, zp);
+    bench_gemm("lin_16_1280_3840_qkv", GEMM_LINEAR, s16, 3840, 1280, 0, 0, EPI_NONE, iters, t, zp);
+    bench_gemm("lin_16_1280_10240_geglu", GEMM_LINEAR, s16, 10240, 1280, 0, 0, EPI_GEGLU, iters, t, zp);
+    bench_gemm("lin_16_5120_1280_res", GEMM_LINEAR, s16, 1280, 5120, 0, 0, EPI_RESIDUAL, iters, t, zp);
+    bench_gemm("lin_16_sc_2560_1280", GEMM_LINEAR, s16, 1280, 1280, 0, 0, EPI_NONE, iters, t, zp, 1280);
+    bench_gemm("lin_kv_768_2560", GEMM_LINEAR, 154, 2560, 768, 0, 0, EPI_NONE, iters, t, zp);
+    // ---- attention ----
+    bench_attn("attn_self_4096_d40", B2, B2, 8, 4096, 4096, 40, iters, t);
+    bench_attn("attn_self_1024_d80", B2, B2, 8, 1024, 1024, 80, iters, t);
+    bench_attn("attn_self_256_d160", B2, B2, 8, 256, 256, 160, iters, t);
+    bench_attn("attn_cross_4096_d40", B2, 2, 8, 4096, 77, 40, iters, t);
+    bench_attn("attn_cross_256_d160", B2, 2, 8, 256, 77, 160, iters, t);
+    // ---- norms ----
+    bench_gn("gn_64_320", B2, 4096, 320, iters, t);
+    bench_gn("gn_16_1280", B2, 256, 1280, iters, t);
+    return 0;
+}

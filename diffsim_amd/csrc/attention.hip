@@ -10,12 +10,22 @@
 //                      three f32 partial sums per workgroup reach HBM and a second fixed-order pass
 //                      folds them (no float atomics => bit-reproducible scores).
 //
-// Tiling: a workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 rows.
-// S^T = K Q^T is computed with K as the MFMA A operand and Q as B ("swapped QK^T"), so a lane
-// holds one query column of S^T in its accumulator registers: the row max/sum are per-lane
-// reductions over registers plus one exchange between the two lane halves, and the accumulator
-// is directly the B operand of O^T = V^T P^T (no LDS round trip for P).  V^T fragments come from
-// the row-major V tile by ds_read_b64_tr_b16 (bf16) or ds_read_b32 (f32).
+// Tiling: a workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 rows and
+// sweeps the keys in 64-row tiles shared through LDS.
+//   - S^T = K Q^T is computed with K as the MFMA A operand and Q as B ("swapped QK^T"), so a lane
+//     holds one query column of S^T in its accumulator registers: the row max is a per-lane
+//     reduction over registers plus one exchange between the two lane halves, and the accumulator
+//     is directly the B operand of O^T = V^T P^T (no LDS round trip for P).
+//   - Q is pre-scaled by log2(e)/sqrt(D) and the S^T accumulators START at -m (the running row
+//     max), so P = exp2(acc) needs no subtract and no multiply: per score element the VALU does
+//     one v_exp, half a v_max3 and half a v_cvt_pk.  O is rescaled only in tiles where some row's
+//     max grew (exact: alpha == 1 for the other rows).
+//   - The softmax denominator comes out of the PV MFMAs: when the head dim leaves a spare column
+//     in the 32-wide d block (D = 40, 72, 80, 16) the staged V tile carries a column of ones, so
+//     row D of O^T accumulates sum(P) and is rescaled together with O.
+//   - V^T fragments come from the row-major V tile by ds_read_b64_tr_b16 (bf16) / ds_read_b32 (f32).
+//   - bf16: next tile's global loads are in flight during the current tile's compute (registers
+//     -> double-buffered LDS, one barrier per tile).  f32 parity mode: simple single buffer.
 // bf16 path: v_mfma_f32_32x32x16_bf16; fp32 parity path: v_mfma_f32_32x32x2_f32 (exact f32).
 #include "common.h"
 
@@ -24,15 +34,26 @@ namespace {
 
 constexpr int KT = 64;   // kv rows per LDS tile
 
-template <typename T, int DP> struct ACfg {
+template <typename T, int D> struct ACfg {
     static constexpr int ES = sizeof(T);
     static constexpr int VEC = 16 / ES;
-    static constexpr int RS = DP * ES + 16;       // LDS row stride: odd number of 16-B slots
-    static constexpr int CPR = DP / VEC;          // 16-B chunks per row
-    static constexpr int NDB = DP / 32;           // 32-wide output blocks over d
-    static constexpr int NKS = DP / 16;           // 16-deep k steps over d
-    static constexpr int TILE = KT * RS;
-    static constexpr int LDS = 2 * TILE;
+    static constexpr int NKS = (D + 15) / 16;     // 16-deep k steps over d (QK^T)
+    static constexpr int NDB = (D + 31) / 32;     // 32-wide output blocks over d (PV)
+    static constexpr int DPL = NDB * 32;          // LDS columns (zero padded)
+    static constexpr bool ONES = D < DPL;         // spare column -> ones column gives the row sum
+    static constexpr int RS = DPL * ES + 16;      // K tile row stride: odd number of 16-B slots (ds_read_b128)
+    // V tile row stride.  bf16: the transposed reads (ds_read_b64_tr_b16) take, per 32-lane half, a
+    // 4-row x 32-column block = 4 rows x 16 dwords; they are conflict-free when the row stride is
+    // 16 or 48 dwords mod 64 (four rows tile the 64 banks).  f32: plain ds_read_b32, same as K.
+    static constexpr int RSV = (ES == 2) ? (((DPL * 2) % 256 == 64 || (DPL * 2) % 256 == 192) ? DPL * 2 : DPL * 2 + 64) : RS;
+    static constexpr int CPR = DPL / VEC;         // 16-B chunks per row
+    static constexpr int TILEK = KT * RS;
+    static constexpr int TILE = (KT * RS + KT * RSV + 1) / 2;   // average, so that 2*TILE = K tile + V tile
+    static constexpr bool PIPE = sizeof(T) == 2;
+    static constexpr int NSR = (KT * CPR + 255) / 256;     // 16-B chunks of K (and of V) per thread per tile
+    static constexpr int LDS = (PIPE ? 4 : 2) * TILE;
+    // waves per SIMD the register budget is held to (occupancy hides the serial MFMA/VALU phases)
+    static constexpr int WPS = (sizeof(T) == 2 && DPL <= 64) ? 3 : ((sizeof(T) == 2 && DPL <= 96) ? 2 : 1);
 };
 
 struct FragF32 { f32x4 lo, hi; };
@@ -47,10 +68,15 @@ __device__ __forceinline__ void zero_frag(FragF32& f) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) f.lo[i] = f.hi[i] = 0.f;
 }
-__device__ __forceinline__ void gload_frag(bf16x8& f, const bf16* p) { f = *reinterpret_cast<const bf16x8*>(p); }
-__device__ __forceinline__ void gload_frag(FragF32& f, const float* p) {
-    f.lo = *reinterpret_cast<const f32x4*>(p);
-    f.hi = *reinterpret_cast<const f32x4*>(p + 4);
+// load 8 consecutive elements and pre-scale them (Q only)
+__device__ __forceinline__ void gload_frag_scaled(bf16x8& f, const bf16* p, float sc) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (bf16)((float)t[i] * sc);
+}
+__device__ __forceinline__ void gload_frag_scaled(FragF32& f, const float* p, float sc) {
+    f.lo = *reinterpret_cast<const f32x4*>(p) * sc;
+    f.hi = *reinterpret_cast<const f32x4*>(p + 4) * sc;
 }
 __device__ __forceinline__ void lload_frag(bf16x8& f, const char* p) { f = *reinterpret_cast<const bf16x8*>(p); }
 __device__ __forceinline__ void lload_frag(FragF32& f, const char* p) {
@@ -67,110 +93,168 @@ __device__ __forceinline__ void mma(const FragF32& a, const FragF32& b, f32x16& 
     for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.hi[j], b.hi[j], c, 0, 0, 0);
 }
 
-// Q fragments of this wave's 32 query rows, resident in registers for the whole kv sweep.
-template <typename T, int DP> struct QFrags { typename FragOf<T>::type f[ACfg<T, DP>::NKS]; };
-template <typename T, int DP> struct OAcc { f32x16 b[ACfg<T, DP>::NDB]; };
+// Q fragments of this wave's 32 query rows (pre-scaled by log2(e)/sqrt(D)), resident in registers.
+template <typename T, int D> struct QFrags { typename FragOf<T>::type f[ACfg<T, D>::NKS]; };
+template <typename T, int D> struct OAcc { f32x16 b[ACfg<T, D>::NDB]; };
 
-template <typename T, int DP>
-__device__ __forceinline__ void load_q(QFrags<T, DP>& qf, const T* qrow /*row base + h*D*/, int D, int half) {
+template <typename T, int D>
+__device__ __forceinline__ void load_q(QFrags<T, D>& qf, const T* qrow /*row base + h*D*/, int half, float scale_log2) {
 #pragma unroll
-    for (int ks = 0; ks < ACfg<T, DP>::NKS; ++ks) {
+    for (int ks = 0; ks < ACfg<T, D>::NKS; ++ks) {
         const int d0 = 16 * ks + 8 * half;
-        if (d0 < D) gload_frag(qf.f[ks], qrow + d0);
+        if (d0 < D) gload_frag_scaled(qf.f[ks], qrow + d0, scale_log2);
         else zero_frag(qf.f[ks]);
     }
 }
 
-// Stage one KT-row tile of K and V (rows >= Nk and columns >= D zero-filled) into LDS.
-template <typename T, int DP>
-__device__ __forceinline__ void stage_kv(char* lds, const T* kb, const T* vb, int ldk, int kv0, int Nk, int D, int tid) {
-    typedef ACfg<T, DP> C;
-    u32x4 z = {0u, 0u, 0u, 0u};
-    for (int idx = tid; idx < KT * C::CPR; idx += 256) {
+// Staging of one KT-row tile of K and V, split in a load half and a store half so the global loads
+// can be issued a whole tile ahead of the LDS writes.  Rows >= Nk and columns >= D are zero; with
+// ONES the V tile gets 1.0 in column D of every valid row.
+template <typename T, int D> struct StageRegs { u32x4 k[ACfg<T, D>::NSR], v[ACfg<T, D>::NSR]; };
+
+template <typename T> __device__ __forceinline__ u32x4 one_chunk();
+template <> __device__ __forceinline__ u32x4 one_chunk<bf16>() { u32x4 r = {0x00003F80u, 0u, 0u, 0u}; return r; }   // bf16 1.0 in element 0
+template <> __device__ __forceinline__ u32x4 one_chunk<float>() { u32x4 r = {0x3F800000u, 0u, 0u, 0u}; return r; }
+
+template <typename T, int D>
+__device__ __forceinline__ void tile_load(StageRegs<T, D>& sr, const T* kb, const T* vb, int ldk, int kv0, int Nk, int tid) {
+    typedef ACfg<T, D> C;
+#pragma unroll
+    for (int i = 0; i < C::NSR; ++i) {
+        const int idx = tid + i * 256;
         const int r = idx / C::CPR, c = idx - r * C::CPR;
         const int kv = kv0 + r;
-        u32x4 kvv = z, vvv = z;
-        if (kv < Nk && c * C::VEC < D) {
-            const size_t off = (size_t)kv * ldk + c * C::VEC;
-            kvv = *reinterpret_cast<const u32x4*>(kb + off);
-            vvv = *reinterpret_cast<const u32x4*>(vb + off);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        sr.k[i] = z;
+        sr.v[i] = z;
+        if (idx < KT * C::CPR && kv < Nk) {
+            if (c * C::VEC < D) {
+                const size_t off = (size_t)kv * ldk + c * C::VEC;
+                sr.k[i] = *reinterpret_cast<const u32x4*>(kb + off);
+                sr.v[i] = *reinterpret_cast<const u32x4*>(vb + off);
+            } else if (C::ONES && c * C::VEC == D) {
+                sr.v[i] = one_chunk<T>();
+            }
         }
-        *reinterpret_cast<u32x4*>(lds + r * C::RS + c * 16) = kvv;
-        *reinterpret_cast<u32x4*>(lds + C::TILE + r * C::RS + c * 16) = vvv;
+    }
+}
+template <typename T, int D>
+__device__ __forceinline__ void tile_store(char* lds, const StageRegs<T, D>& sr, int tid) {
+    typedef ACfg<T, D> C;
+#pragma unroll
+    for (int i = 0; i < C::NSR; ++i) {
+        const int idx = tid + i * 256;
+        const int r = idx / C::CPR, c = idx - r * C::CPR;
+        if (idx < KT * C::CPR) {
+            *reinterpret_cast<u32x4*>(lds + r * C::RS + c * 16) = sr.k[i];
+            *reinterpret_cast<u32x4*>(lds + C::TILEK + r * C::RSV + c * 16) = sr.v[i];
+        }
     }
 }
 
 // One full attention of this wave's 32 query rows against Nk keys.  On return o[db][r] holds the
 // NORMALISED output O^T[d = db*32 + (r&3)+8(r>>2)+4*half][q = lane&31].  All 256 threads of the
 // workgroup must call it together (it contains workgroup barriers).
-template <typename T, int DP>
-__device__ __forceinline__ void attend(const QFrags<T, DP>& qfr, const T* kb, const T* vb, int ldk, int Nk, int D,
-                                       float scale_log2, char* lds, OAcc<T, DP>& oacc) {
+template <typename T, int D>
+__device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, const T* vb, int ldk, int Nk, char* lds,
+                                       OAcc<T, D>& oacc) {
+    typedef ACfg<T, D> C;
+    typedef typename FragOf<T>::type Frag;
     const auto& qf = qfr.f;
     auto& o = oacc.b;
-    typedef ACfg<T, DP> C;
-    typedef typename FragOf<T>::type Frag;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = 0.f;          // running row max (log2 units); meaningful after tile 0
+    float l_run = 0.f;          // used only when !ONES
 
     const int ntiles = (Nk + KT - 1) / KT;
+    StageRegs<T, D> sr;
+    if constexpr (C::PIPE) {
+        tile_load<T, D>(sr, kb, vb, ldk, 0, Nk, tid);
+        __syncthreads();        // a previous attend() of this workgroup may still be reading the buffers
+    }
+    char* const lds0 = lds;
     for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();                                   // previous tile fully consumed
-        stage_kv<T, DP>(lds, kb, vb, ldk, kt * KT, Nk, D, tid);
-        __syncthreads();
+        if constexpr (C::PIPE) {
+            // buffer (kt&1) was last read in iteration kt-2; every wave has passed barrier kt-1 since
+            lds = lds0 + (kt & 1) * 2 * C::TILE;
+            tile_store<T, D>(lds, sr, tid);
+            __syncthreads();
+            if (kt + 1 < ntiles) tile_load<T, D>(sr, kb, vb, ldk, (kt + 1) * KT, Nk, tid);
+        } else {
+            __syncthreads();                               // previous tile fully consumed
+            tile_load<T, D>(sr, kb, vb, ldk, kt * KT, Nk, tid);
+            tile_store<T, D>(lds, sr, tid);
+            __syncthreads();
+        }
 
-        // ---- S^T = K Q^T for the two 32-row kv blocks ------------------------------------
+        // ---- S'^T = K Q^T - m for the two 32-row kv blocks (accumulators start at -m) ----------
         f32x16 s[2];
+        const float cinit = -m_run;
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[jb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[jb][r] = cinit;
             const char* krow = lds + (jb * 32 + l31) * C::RS + half * 8 * C::ES;
 #pragma unroll
             for (int ks = 0; ks < C::NKS; ++ks) {
-                if (ks * 16 < D) {
-                    Frag kf;
-                    lload_frag(kf, krow + ks * 16 * C::ES);
-                    mma(kf, qf[ks], s[jb]);
-                }
+                Frag kf;
+                lload_frag(kf, krow + ks * 16 * C::ES);
+                mma(kf, qf[ks], s[jb]);
             }
+        }
+        if (kt * KT + KT > Nk) {                           // ragged last tile only
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = kt * KT + jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (kv >= Nk) s[jb][r] = -INFINITY;
+                }
         }
         // ---- online softmax (per query column == per lane) ---------------------------------
         float tmax = -INFINITY;
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kv = kt * KT + jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (kv >= Nk) s[jb][r] = -INFINITY;
-                tmax = fmaxf(tmax, s[jb][r]);
-            }
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[jb][r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2);
-        const float mb = m_new * scale_log2;
-        float psum = 0.f;
+        // tmax is relative to m_run.  Tile 0 always re-bases; later tiles only when some row's max
+        // grew (the running max settles after a few tiles) -- exact, not a threshold.
+        if (kt == 0 || !__all(tmax <= 0.f)) {
+            const float delta = kt == 0 ? tmax : fmaxf(tmax, 0.f);
+            m_run += delta;
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[jb][r] -= delta;
+            if (kt != 0) {
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                l_run *= alpha;
+#pragma unroll
+                for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+            }
+        }
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(s[jb][r], scale_log2, -mb));
-                s[jb][r] = pv;
-                psum += pv;
-            }
-        l_run = fmaf(l_run, alpha, psum);
-        m_run = m_new;
+            for (int r = 0; r < 16; ++r) s[jb][r] = __builtin_amdgcn_exp2f(s[jb][r]);
+        if constexpr (!C::ONES) {
+            float psum = 0.f;
 #pragma unroll
-        for (int db = 0; db < C::NDB; ++db)
+            for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+                for (int r = 0; r < 16; ++r) psum += s[jb][r];
+            l_run += psum;
+        }
 
         // ---- O^T += V^T P^T ---------------------------------------------------------------
-        const char* vt = lds + C::TILE;
+        const char* vt = lds + C::TILEK;
         if constexpr (sizeof(T) == 2) {
             // transposed read: per 16-lane group a 4x16 block; lane 4q+p supplies row q, cols 4p..4p+3
             const int i16 = lane & 15, g = lane >> 4;
@@ -183,20 +267,17 @@ __device__ __forceinline__ void attend(const QFrags<T, DP>& qfr, const T* kb, co
                     bf16x8 pf;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pf[j] = (bf16)s[jb][8 * s2 + j];
-                    const char* vbase = vt + (jb * 32 + 16 * s2 + trow) * C::RS + tcol * 2;
+                    const char* vbase = vt + (jb * 32 + 16 * s2 + trow) * C::RSV + tcol * 2;
 #pragma unroll
                     for (int db = 0; db < C::NDB; ++db) {
-                        if (db * 32 < D) {
-                            const char* pa = vbase + db * 64;
-                            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                                (__attribute__((address_space(3))) bf16x4*)(pa));
-                            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                                (__attribute__((address_space(3))) bf16x4*)(pa + 8 * C::RS));
-                            bf16x8 vf;
+                        const char* pa = vbase + db * 64;
+                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa));
+                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)(pa + 8 * C::RSV));
+                        bf16x8 vf;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
-                            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
-                        }
+                        for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
                     }
                 }
             }
@@ -206,19 +287,27 @@ __device__ __forceinline__ void attend(const QFrags<T, DP>& qfr, const T* kb, co
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const char* vrow = vt + row * C::RS + l31 * 4;
+                    const char* vrow = vt + row * C::RSV + l31 * 4;
 #pragma unroll
                     for (int db = 0; db < C::NDB; ++db) {
-                        if (db * 32 < D) {
-                            const float a = *reinterpret_cast<const float*>(vrow + db * 128);
-                            o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[jb][r], o[db], 0, 0, 0);
-                        }
+                        const float a = *reinterpret_cast<const float*>(vrow + db * 128);
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[jb][r], o[db], 0, 0, 0);
                     }
                 }
             }
         }
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    float l_tot;
+    if constexpr (C::ONES) {
+        // row D of O^T = sum(P): block D/32, in-block row D%32 = (r&3)+8(r>>2)+4*half
+        constexpr int RB = D / 32, RR = D % 32;
+        constexpr int RH = (RR >> 2) & 1, REG = (RR & 3) + 4 * (RR >> 3);
+        const float mine = o[RB][REG];
+        const float other = __shfl_xor(mine, 32);
+        l_tot = (half == RH) ? mine : other;
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32);
+    }
     const float inv = 1.0f / l_tot;
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db)
@@ -227,30 +316,29 @@ __device__ __forceinline__ void attend(const QFrags<T, DP>& qfr, const T* kb, co
 }
 
 // grid (ceil(Nq/128), H, B)
-template <typename T, int DP>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p, const float scale_log2) {
-    typedef ACfg<T, DP> C;
-    typedef typename FragOf<T>::type Frag;
+template <typename T, int D>
+__global__ __launch_bounds__(256, (ACfg<T, D>::WPS)) void attn_kernel(const AttnArgs p, const float scale_log2) {
+    typedef ACfg<T, D> C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z;
     const int q = blockIdx.x * 128 + wave * 32 + l31;
     const int qc = q < p.Nq ? q : p.Nq - 1;
-    const T* qrow = (const T*)p.q + ((size_t)b * p.Nq + qc) * p.ldq + h * p.D;
-    QFrags<T, DP> qf;
-    load_q<T, DP>(qf, qrow, p.D, half);
-    const size_t kvoff = (size_t)(b % p.Bkv) * p.Nk * p.ldk + h * p.D;
-    OAcc<T, DP> oa;
-    attend<T, DP>(qf, (const T*)p.k + kvoff, (const T*)p.v + kvoff, p.ldk, p.Nk, p.D, scale_log2, smem, oa);
+    const T* qrow = (const T*)p.q + ((size_t)b * p.Nq + qc) * p.ldq + h * D;
+    QFrags<T, D> qf;
+    load_q<T, D>(qf, qrow, half, scale_log2);
+    const size_t kvoff = (size_t)(b % p.Bkv) * p.Nk * p.ldk + h * D;
+    OAcc<T, D> oa;
+    attend<T, D>(qf, (const T*)p.k + kvoff, (const T*)p.v + kvoff, p.ldk, p.Nk, smem, oa);
     auto& o = oa.b;
     if (q < p.Nq) {
-        T* orow = (T*)p.out + ((size_t)b * p.Nq + q) * p.ldo + h * p.D;
+        T* orow = (T*)p.out + ((size_t)b * p.Nq + q) * p.ldo + h * D;
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d = db * 32 + 8 * g + 4 * half;
-                if (d < p.D) {
+                if (d < D) {
                     if constexpr (sizeof(T) == 2) {
                         bf16x4 v4;
 #pragma unroll
@@ -269,15 +357,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p, const float
 
 // ---- fused score tail ----------------------------------------------------------------------
 // grid (ceil(N/128), B*H, n_pairs*2); partial layout [pair][dir][bh][qtile][4] f32
-template <typename T, int DP>
+template <typename T, int D>
 __global__ __launch_bounds__(256) void pair_tail_kernel(const T* __restrict__ qg, const T* __restrict__ kg,
                                                         const T* __restrict__ vg, const int32_t* __restrict__ idx_a,
-                                                        const int32_t* __restrict__ idx_b, int B, int H, int N, int D,
+                                                        const int32_t* __restrict__ idx_b, int B, int H, int N,
                                                         float scale_log2, int mse, float* __restrict__ part) {
-    typedef ACfg<T, DP> C;
-    typedef typename FragOf<T>::type Frag;
+    typedef ACfg<T, D> C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float red[4][3];
+    __shared__ float red[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int pair = blockIdx.z >> 1, dir = blockIdx.z & 1;
@@ -289,11 +376,11 @@ __global__ __launch_bounds__(256) void pair_tail_kernel(const T* __restrict__ qg
     const int q = blockIdx.x * 128 + wave * 32 + l31;
     const int qc = q < N ? q : N - 1;
     const size_t boff = (size_t)b * N * ld + h * D;
-    QFrags<T, DP> qf;
-    load_q<T, DP>(qf, qg + iq * img + boff + (size_t)qc * ld, D, half);
-    OAcc<T, DP> osa, oxa;
-    attend<T, DP>(qf, kg + iq * img + boff, vg + iq * img + boff, ld, N, D, scale_log2, smem, osa);
-    attend<T, DP>(qf, kg + ix * img + boff, vg + ix * img + boff, ld, N, D, scale_log2, smem, oxa);
+    QFrags<T, D> qf;
+    load_q<T, D>(qf, qg + iq * img + boff + (size_t)qc * ld, half, scale_log2);
+    OAcc<T, D> osa, oxa;
+    attend<T, D>(qf, kg + iq * img + boff, vg + iq * img + boff, ld, N, smem, osa);
+    attend<T, D>(qf, kg + ix * img + boff, vg + ix * img + boff, ld, N, smem, oxa);
     auto& os = osa.b;
     auto& ox = oxa.b;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -347,44 +434,48 @@ __global__ void pair_finish_kernel(const float* __restrict__ part, int n_pairs, 
     out[p] = (float)(res * 0.5);
 }
 
-template <typename T, int DP>
-int launch_attn_dp(const AttnArgs& a, hipStream_t s) {
-    typedef ACfg<T, DP> C;
+inline float scale_log2_of(int D) { return (1.0f / sqrtf((float)D)) * 1.4426950408889634f; }
+
+template <typename T, int D>
+int launch_attn_d(const AttnArgs& a, hipStream_t s) {
+    typedef ACfg<T, D> C;
     static bool attr_done = false;
-    auto kern = attn_kernel<T, DP>;
+    auto kern = attn_kernel<T, D>;
     if (!attr_done) {
         DSIM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         attr_done = true;
     }
-    const float scale_log2 = (1.0f / sqrtf((float)a.D)) * 1.4426950408889634f;
-    hipLaunchKernelGGL(kern, dim3((a.Nq + 127) / 128, a.H, a.B), dim3(256), C::LDS, s, a, scale_log2);
+    hipLaunchKernelGGL(kern, dim3((a.Nq + 127) / 128, a.H, a.B), dim3(256), C::LDS, s, a, scale_log2_of(D));
     DSIM_HIP_CHECK(hipGetLastError());
     return DSIM_OK;
 }
 
+// head dims of the supported graphs: SD1.5 40/80/160, SDXL 64, DiT-XL/2 72, test configs 16/32/64
+#define DSIM_FOR_EACH_D(X) X(16) X(32) X(40) X(64) X(72) X(80) X(160)
+
 template <typename T>
 int launch_attn_t(const AttnArgs& a, hipStream_t s) {
-    if (a.D <= 32) return launch_attn_dp<T, 32>(a, s);
-    if (a.D <= 64) return launch_attn_dp<T, 64>(a, s);
-    if (a.D <= 96) return launch_attn_dp<T, 96>(a, s);
-    if (a.D <= 160) return launch_attn_dp<T, 160>(a, s);
-    return DSIM_ERR_INVALID;
+    switch (a.D) {
+#define X(d) case d: return launch_attn_d<T, d>(a, s);
+        DSIM_FOR_EACH_D(X)
+#undef X
+        default: return DSIM_ERR_INVALID;
+    }
 }
 
-template <typename T, int DP>
-int launch_tail_dp(const void* q, const void* k, const void* v, const int32_t* ia, const int32_t* ib, int n_pairs,
-                   int B, int H, int N, int D, int mse, float* out, void* scratch, hipStream_t s) {
-    typedef ACfg<T, DP> C;
+template <typename T, int D>
+int launch_tail_d(const void* q, const void* k, const void* v, const int32_t* ia, const int32_t* ib, int n_pairs,
+                  int B, int H, int N, int mse, float* out, void* scratch, hipStream_t s) {
+    typedef ACfg<T, D> C;
     static bool attr_done = false;
-    auto kern = pair_tail_kernel<T, DP>;
+    auto kern = pair_tail_kernel<T, D>;
     if (!attr_done) {
         DSIM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         attr_done = true;
     }
-    const float scale_log2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
     const int qt = (N + 127) / 128;
     hipLaunchKernelGGL(kern, dim3(qt, B * H, n_pairs * 2), dim3(256), C::LDS, s, (const T*)q, (const T*)k,
-                       (const T*)v, ia, ib, B, H, N, D, scale_log2, mse, (float*)scratch);
+                       (const T*)v, ia, ib, B, H, N, scale_log2_of(D), mse, (float*)scratch);
     hipLaunchKernelGGL(pair_finish_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, s, (const float*)scratch, n_pairs,
                        qt * B * H, mse, (double)B * H * N * D, out);
     DSIM_HIP_CHECK(hipGetLastError());
@@ -394,11 +485,12 @@ int launch_tail_dp(const void* q, const void* k, const void* v, const int32_t* i
 template <typename T>
 int launch_tail_t(const void* q, const void* k, const void* v, const int32_t* ia, const int32_t* ib, int n_pairs,
                   int B, int H, int N, int D, int mse, float* out, void* scratch, hipStream_t s) {
-    if (D <= 32) return launch_tail_dp<T, 32>(q, k, v, ia, ib, n_pairs, B, H, N, D, mse, out, scratch, s);
-    if (D <= 64) return launch_tail_dp<T, 64>(q, k, v, ia, ib, n_pairs, B, H, N, D, mse, out, scratch, s);
-    if (D <= 96) return launch_tail_dp<T, 96>(q, k, v, ia, ib, n_pairs, B, H, N, D, mse, out, scratch, s);
-    if (D <= 160) return launch_tail_dp<T, 160>(q, k, v, ia, ib, n_pairs, B, H, N, D, mse, out, scratch, s);
-    return DSIM_ERR_INVALID;
+    switch (D) {
+#define X(d) case d: return launch_tail_d<T, d>(q, k, v, ia, ib, n_pairs, B, H, N, mse, out, scratch, s);
+        DSIM_FOR_EACH_D(X)
+#undef X
+        default: return DSIM_ERR_INVALID;
+    }
 }
 
 }  // namespace

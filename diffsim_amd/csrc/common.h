@@ -50,7 +50,8 @@ struct GemmArgs {
     const void* residual = nullptr;             // [M][ldo]
     void* out = nullptr;
     int ldo = 0;
-    const void* zero_page = nullptr;            // >= 16 zero bytes (padding source)
+    const void* zero_page = nullptr;            // >= 16 zero bytes (kept for ABI stability; padding now comes from OOB buffer reads)
+    unsigned a0_bytes = 0, a1_bytes = 0, w_bytes = 0;   // filled by launch_gemm: operand extents for the buffer descriptors
 };
 int launch_gemm(const GemmArgs& a, int dtype, hipStream_t s);
 extern int g_force_bm;     // 0 = heuristic; 128/256 force the row tile (micro-benchmark A/B only)

@@ -122,12 +122,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p, const int t
 
     const int lrow = lane >> 3;                                   // row inside an 8-row DMA piece
     const int wrow = wave * 8 + lrow;                             // row inside a 32-row group
-    const int cel = ((lane & 7) ^ ((wrow >> 1) & 7)) * VEC;       // swizzled source chunk (elements)
+    const unsigned celb = ((lane & 7) ^ ((wrow >> 1) & 7)) * 16;  // swizzled source chunk (bytes)
+    constexpr unsigned OOB = 0x80000000u;                         // voffset beyond every buffer -> DMA writes zeros
+
+    // Buffer descriptors: every per-lane part of an address lives in a 32-bit voffset, the K
+    // advance in a scalar soffset, so the steady-state staging costs no VALU at all, and rows that
+    // must read as zero (conv padding, ragged M/N edges) simply carry an out-of-range voffset.
+    const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A0, 0, (int)p.a0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A1 ? p.A1 : p.A0), 0, (int)p.a1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)p.w_bytes, 0x00020000);
 
     // ---- per-thread A row state ----------------------------------------------------------
     int a_iy0[NA], a_ix0[NA];
-    unsigned a_base[NA], a_off[NA];
-    unsigned a_ok = 0;   // bit i: row i valid for the current tap
+    unsigned a_base[NA], a_voff[NA];
     const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -139,62 +146,60 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p, const int t
             a_iy0[i] = (m < p.M) ? oy * p.stride - 1 : -(1 << 20);
             a_ix0[i] = ox * p.stride - 1;
             a_base[i] = (unsigned)b * (unsigned)(p.Hin * p.Win);
+            a_voff[i] = OOB;
         } else {
             a_iy0[i] = a_ix0[i] = 0;
-            a_base[i] = (unsigned)m;
-            if (m < p.M) a_ok |= 1u << i;
+            a_base[i] = (m < p.M) ? (unsigned)m : OOB;
+            a_voff[i] = (m < p.M) ? (unsigned)m * (unsigned)p.C0 * (unsigned)sizeof(T) + celb : OOB;
         }
-        a_off[i] = 0;
     }
-    unsigned b_off[NB];
-    unsigned b_ok = 0;
+    unsigned b_voff[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int n = n0 + i * 32 + wrow;
-        b_off[i] = (unsigned)n * (unsigned)p.K + cel;
-        if (n < p.N) b_ok |= 1u << i;
+        b_voff[i] = (n < p.N) ? (unsigned)n * (unsigned)p.K * (unsigned)sizeof(T) + celb : OOB;
     }
-    const char* const zp = (const char*)p.zero_page;
 
     auto stage = [&](int t, int buf) {
         char* sa = smem + buf * STAGE;
         char* sb = sa + A_BYTES;
         const int k0 = t * BK;
-        const char* abase;
-        unsigned koff;
+        int soff;
+        bool second = false;
         if (MODE == GEMM_CONV3) {
             const int tap = k0 / p.C0;
-            koff = k0 - tap * p.C0;
-            abase = (const char*)p.A0;
+            const int koff = k0 - tap * p.C0;
+            soff = koff * (int)sizeof(T);
             if (koff == 0) {   // first K tile of a tap: re-derive the gathered pixel of every row
                 const int ky = tap / 3, kx = tap - ky * 3;
-                a_ok = 0;
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
                     const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
                     const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-                    a_ok |= ok ? (1u << i) : 0u;
                     const unsigned pix = a_base[i] + (unsigned)((iy >> p.ups) * p.Win + (ix >> p.ups));
-                    a_off[i] = pix * (unsigned)p.C0 + cel;
+                    a_voff[i] = ok ? pix * (unsigned)p.C0 * (unsigned)sizeof(T) + celb : OOB;
                 }
             }
         } else {
-            int cs;
-            if (k0 < p.C0) { abase = (const char*)p.A0; cs = p.C0; koff = k0; }
-            else           { abase = (const char*)p.A1; cs = p.C1; koff = k0 - p.C0; }
+            second = k0 >= p.C0;
+            soff = (second ? k0 - p.C0 : k0) * (int)sizeof(T);
+            if (second && k0 == p.C0) {   // first K tile of the concatenated second source
 #pragma unroll
-            for (int i = 0; i < NA; ++i) a_off[i] = a_base[i] * (unsigned)cs + cel;
+                for (int i = 0; i < NA; ++i)
+                    a_voff[i] = a_base[i] != OOB ? a_base[i] * (unsigned)p.C1 * (unsigned)sizeof(T) + celb : OOB;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const char* src = ((a_ok >> i) & 1u) ? abase + (size_t)(a_off[i] + koff) * sizeof(T) : zp;
-            glds16(src, sa + (i * 4 + wave) * 1024);
+            auto lds = (__attribute__((address_space(3))) void*)(sa + (i * 4 + wave) * 1024);
+            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, lds, 16, (int)a_voff[i], soff, 0, 0);
+            else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, lds, 16, (int)a_voff[i], soff, 0, 0);
         }
+        const int soffw = k0 * (int)sizeof(T);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const char* src = ((b_ok >> i) & 1u) ? (const char*)p.W + (size_t)(b_off[i] + k0) * sizeof(T) : zp;
-            glds16(src, sb + (i * 4 + wave) * 1024);
-        }
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(sb + (i * 4 + wave) * 1024),
+                                                     16, (int)b_voff[i], soffw, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -218,18 +223,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p, const int t
         if (t + 1 < nk) stage(t + 1, cur ^ 1);
         const char* sa = smem + cur * STAGE + wave * (BM / 4) * 128 + frow;
         const char* sb = smem + cur * STAGE + A_BYTES + frow;
+        // fragments are register double-buffered: the ds_reads of step kk+1 are in flight while the
+        // MFMAs of step kk run, so only the first read of a K tile exposes LDS latency
+        Frag fa[2][TM], fb[2][TN];
+        auto load_set = [&](int kk, int set) {
+            const int c0 = (sizeof(T) == 2) ? (2 * kk + half) : (4 * kk + 2 * half);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) load_frag(fa[set][i], sa + i * 32 * 128, c0, sw);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) load_frag(fb[set][j], sb + j * 32 * 128, c0, sw);
+        };
+        load_set(0, 0);
 #pragma unroll
         for (int kk = 0; kk < KSUB; ++kk) {
-            const int c0 = (sizeof(T) == 2) ? (2 * kk + half) : (4 * kk + 2 * half);
-            Frag a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) load_frag(a[i], sa + i * 32 * 128, c0, sw);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) load_frag(b[j], sb + j * 32 * 128, c0, sw);
+            if (kk + 1 < KSUB) load_set(kk + 1, (kk + 1) & 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) mma(b[j], a[i], acc[i][j]);   // D^T: rows = n (registers), cols = m (lane)
+                for (int j = 0; j < TN; ++j)
+                    mma(fb[kk & 1][j], fa[kk & 1][i], acc[i][j]);   // D^T: rows = n (registers), cols = m (lane)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -346,7 +358,21 @@ int launch_one(const GemmArgs& a, hipStream_t s) {
         attr_done = true;
     }
     const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(256), LDS, s, a, tilesN);
+    // byte extents of the three operands for the buffer descriptors (32-bit offsets: < 2 GiB each)
+    GemmArgs g = a;
+    const size_t es = sizeof(T);
+    size_t a0b, a1b = 16;
+    if (MODE == GEMM_CONV3) {
+        const size_t bimg = (size_t)a.M / ((size_t)a.Hout * a.Wout);
+        a0b = bimg * a.Hin * a.Win * a.C0 * es;
+    } else {
+        a0b = (size_t)a.M * a.C0 * es;
+        if (a.A1) a1b = (size_t)a.M * a.C1 * es;
+    }
+    const size_t wb = (size_t)a.N * a.K * es;
+    if (a0b >= 0x7fffffffull || a1b >= 0x7fffffffull || wb >= 0x7fffffffull) return DSIM_ERR_INVALID;
+    g.a0_bytes = (unsigned)a0b; g.a1_bytes = (unsigned)a1b; g.w_bytes = (unsigned)wb;
+    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(256), LDS, s, g, tilesN);
     DSIM_HIP_CHECK(hipGetLastError());
     return DSIM_OK;
 }

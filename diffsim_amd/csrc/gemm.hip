@@ -92,20 +92,27 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 
 // LDS: two staging buffers for the K loop; the epilogue's four wave-private transpose slabs reuse them
-template <typename T, int BM, int BN, bool GEGLU>
+template <typename T, int BM, int BN, bool GEGLU, int NW, int NST>
 constexpr int gemm_lds_bytes() {
-    const int stage2 = 2 * (BM + BN) * 128;
-    const int epi = 4 * 32 * ((GEGLU ? BN / 2 : BN) * (int)sizeof(T) + 16);
-    return stage2 > epi ? stage2 : epi;
+    const int stages = NST * (BM + BN) * 128;
+    const int epi = NW * 32 * ((GEGLU ? BN / 2 : BN) * (int)sizeof(T) + 16);
+    return stages > epi ? stages : epi;
 }
 
-template <typename T, int BM, int BN, int MODE, bool GEGLU>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p, const int tilesN) {
+// NW waves stacked along M (each owns BM/NW rows x BN columns); NST LDS stages:
+//   NST == 2: stage t+1 is issued at the top of step t and drained (vmcnt(0)) at its end;
+//   NST == 3: stage t+2 is issued at the top of step t and only stage t+1 -- a counted vmcnt --
+//             must have landed before the step's barrier, so a whole K tile of loads stays in
+//             flight across every barrier (raw s_barrier: __syncthreads() would drain the DMA).
+template <typename T, int BM, int BN, int MODE, bool GEGLU, int NW, int NST>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const GemmArgs p, const int tilesN) {
     constexpr int BK = Traits<T>::BK;
     constexpr int KSUB = Traits<T>::KSUB;
     constexpr int VEC = Traits<T>::VEC;
-    constexpr int TM = BM / 128, TN = BN / 32;
-    constexpr int NA = BM / 32, NB = BN / 32;
+    constexpr int TM = BM / (NW * 32), TN = BN / 32;
+    constexpr int NA = BM / (NW * 8);                      // 8-row DMA pieces of A per wave per stage
+    constexpr int NBP = BN / 8;                            // 8-row DMA pieces of B per stage (all waves)
+    constexpr int NB = (NBP + NW - 1) / NW;                // ... per wave (the last one may be partial)
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     typedef typename FragOf<T>::type Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p, const int t
     const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int m = m0 + i * 32 + wrow;
+        const int m = m0 + i * (NW * 8) + wrow;
         if (MODE == GEMM_CONV3) {
             const int hw = p.Hout * p.Wout;
             const int b = m / hw, rem = m - b * hw;
@@ -156,9 +163,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p, const int t
     unsigned b_voff[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int n = n0 + i * 32 + wrow;
+        const int n = n0 + i * (NW * 8) + wrow;
         b_voff[i] = (n < p.N) ? (unsigned)n * (unsigned)p.K * (unsigned)sizeof(T) + celb : OOB;
     }
+    // B pieces this wave really issues per stage (wave-uniform): the tail piece exists only for
+    // the first NBP % NW waves
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool b_tail = (NBP % NW == 0) || wave_u < (NBP % NW);
 
     auto stage = [&](int t, int buf) {
         char* sa = smem + buf * STAGE;
@@ -191,15 +202,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p, const int t
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            auto lds = (__attribute__((address_space(3))) void*)(sa + (i * 4 + wave) * 1024);
+            auto lds = (__attribute__((address_space(3))) void*)(sa + (i * NW + wave) * 1024);
             if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, lds, 16, (int)a_voff[i], soff, 0, 0);
             else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, lds, 16, (int)a_voff[i], soff, 0, 0);
         }
         const int soffw = k0 * (int)sizeof(T);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(sb + (i * 4 + wave) * 1024),
-                                                     16, (int)b_voff[i], soffw, 0, 0);
+            if (i + 1 < NB || b_tail)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(sb + (i * NW + wave) * 1024),
+                                                         16, (int)b_voff[i], soffw, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -215,14 +227,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p, const int t
     const int sw = (lane >> 1) & 7;                  // == (row>>1)&7 for row = 32*x + (lane&31)
     const int frow = (lane & 31) * 128;
 
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) stage(t + 1, cur ^ 1);
-        const char* sa = smem + cur * STAGE + wave * (BM / 4) * 128 + frow;
-        const char* sb = smem + cur * STAGE + A_BYTES + frow;
+    auto compute = [&](int buf) {
+        const char* sa = smem + buf * STAGE + wave * (BM / NW) * 128 + frow;
+        const char* sb = smem + buf * STAGE + A_BYTES + frow;
         // fragments are register double-buffered: the ds_reads of step kk+1 are in flight while the
         // MFMAs of step kk run, so only the first read of a K tile exposes LDS latency
         Frag fa[2][TM], fb[2][TN];
@@ -237,14 +244,48 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p, const int t
 #pragma unroll
         for (int kk = 0; kk < KSUB; ++kk) {
             if (kk + 1 < KSUB) load_set(kk + 1, (kk + 1) & 1);
+            // pin the order "all reads of step kk+1, then all MFMAs of step kk": left alone, hipcc
+            // sinks each ds_read to just before its MFMA and every MFMA then waits out LDS latency
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     mma(fb[kk & 1][j], fa[kk & 1][i], acc[i][j]);   // D^T: rows = n (registers), cols = m (lane)
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+
+    if constexpr (NST == 2) {
+        stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        for (int t = 0; t < nk; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nk) stage(t + 1, cur ^ 1);
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        // loads of one stage by this wave: NA + NB (or NB-1 without the tail piece)
+        stage(0, 0);
+        if (nk > 1) stage(1, 1);
+        int buf = 0;
+        for (int t = 0; t < nk; ++t) {
+            // stage t must have landed; the newer stage t+1 (if any) may stay in flight
+            if (t + 1 < nk) {
+                if (b_tail) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+                else        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB - 1) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();       // every wave's share of stage t is in LDS; step t-1 fully consumed
+            if (t + 2 < nk) stage(t + 2, buf == 0 ? 2 : buf - 1);      // into the buffer step t-1 read
+            compute(buf);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        __builtin_amdgcn_s_barrier();           // all waves done with the last stage before the epilogue reuses LDS
     }
 
     // ---- epilogue -------------------------------------------------------------------------
@@ -299,7 +340,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p, const int t
             }
         }
         // read-back phase (same wave: LDS operations of one wave execute in order)
-        const int mrow0 = m0 + wave * (BM / 4) + i * 32;
+        const int mrow0 = m0 + wave * (BM / NW) + i * 32;
         for (int idx = lane; idx < 32 * CPR; idx += 64) {
             const int row = idx / CPR, c = idx - row * CPR;
             const int m = mrow0 + row, ncol = c * VEC;
@@ -348,11 +389,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p, const int t
     }
 }
 
-template <typename T, int BM, int BN, int MODE, bool GEGLU>
+template <typename T, int BM, int BN, int MODE, bool GEGLU, int NW = 4, int NST = 2>
 int launch_one(const GemmArgs& a, hipStream_t s) {
-    constexpr int LDS = gemm_lds_bytes<T, BM, BN, GEGLU>();
+    constexpr int LDS = gemm_lds_bytes<T, BM, BN, GEGLU, NW, NST>();
+    static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_done = false;   // one handle per device / one host thread per handle
-    auto kern = gemm_kernel<T, BM, BN, MODE, GEGLU>;
+    auto kern = gemm_kernel<T, BM, BN, MODE, GEGLU, NW, NST>;
     if (!attr_done) {
         DSIM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_done = true;
@@ -372,7 +414,7 @@ int launch_one(const GemmArgs& a, hipStream_t s) {
     const size_t wb = (size_t)a.N * a.K * es;
     if (a0b >= 0x7fffffffull || a1b >= 0x7fffffffull || wb >= 0x7fffffffull) return DSIM_ERR_INVALID;
     g.a0_bytes = (unsigned)a0b; g.a1_bytes = (unsigned)a1b; g.w_bytes = (unsigned)wb;
-    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(256), LDS, s, g, tilesN);
+    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(NW * 64), LDS, s, g, tilesN);
     DSIM_HIP_CHECK(hipGetLastError());
     return DSIM_OK;
 }
@@ -396,19 +438,21 @@ int launch_typed(const GemmArgs& a, hipStream_t s) {
     int bm, bn;
     gemm_tile_choice(a, &bm, &bn);
     const bool big = bm == 256, n160 = bn == 160;
-    if (a.epi == EPI_GEGLU)
-        return big ? launch_one<T, 256, 128, GEMM_LINEAR, true>(a, s)
-                   : launch_one<T, 128, 128, GEMM_LINEAR, true>(a, s);
-    if (a.mode == GEMM_CONV3) {
-        if (n160) return big ? launch_one<T, 256, 160, GEMM_CONV3, false>(a, s)
-                             : launch_one<T, 128, 160, GEMM_CONV3, false>(a, s);
-        return big ? launch_one<T, 256, 128, GEMM_CONV3, false>(a, s)
-                   : launch_one<T, 128, 128, GEMM_CONV3, false>(a, s);
+    if constexpr (sizeof(T) == 2) {
+        // bf16, 256-row tiles: 8 waves, 3-stage LDS ring with a K tile of loads in flight across barriers
+        if (big) {
+            if (a.epi == EPI_GEGLU) return launch_one<T, 256, 128, GEMM_LINEAR, true, 8, 3>(a, s);
+            if (a.mode == GEMM_CONV3)
+                return n160 ? launch_one<T, 256, 160, GEMM_CONV3, false, 8, 3>(a, s)
+                            : launch_one<T, 256, 128, GEMM_CONV3, false, 8, 3>(a, s);
+            return n160 ? launch_one<T, 256, 160, GEMM_LINEAR, false, 8, 3>(a, s)
+                        : launch_one<T, 256, 128, GEMM_LINEAR, false, 8, 3>(a, s);
+        }
     }
-    if (n160) return big ? launch_one<T, 256, 160, GEMM_LINEAR, false>(a, s)
-                         : launch_one<T, 128, 160, GEMM_LINEAR, false>(a, s);
-    return big ? launch_one<T, 256, 128, GEMM_LINEAR, false>(a, s)
-               : launch_one<T, 128, 128, GEMM_LINEAR, false>(a, s);
+    if (a.epi == EPI_GEGLU) return launch_one<T, 128, 128, GEMM_LINEAR, true>(a, s);
+    if (a.mode == GEMM_CONV3)
+        return n160 ? launch_one<T, 128, 160, GEMM_CONV3, false>(a, s) : launch_one<T, 128, 128, GEMM_CONV3, false>(a, s);
+    return n160 ? launch_one<T, 128, 160, GEMM_LINEAR, false>(a, s) : launch_one<T, 128, 128, GEMM_LINEAR, false>(a, s);
 }
 
 }  // namespace

@@ -20,14 +20,23 @@ namespace dsim {
 // tile choice: 160-wide tiles when N allows (every SD channel count is a multiple of 160),
 // 256-row tiles once they still give >= one workgroup per CU.
 int g_force_bm = 0;
+// Tile choice.  Small problems: 128-row tiles, 4 waves, two workgroups per CU (160-wide when N
+// allows -- every SD channel count is a multiple of 160 -- else 128).  bf16 problems with enough
+// 256-row tiles to fill the chip: 256 x 320 (or 256 x 256) tiles, 8 waves as 4 x 2.
 void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn) {
-    const bool n160 = (a.N % 160 == 0) && a.epi != EPI_GEGLU;
-    *bn = n160 ? 160 : 128;
-    // 128-row tiles: two workgroups per CU (<= 74 KB LDS each), so one workgroup's epilogue and
-    // tile-boundary bubbles overlap the other's loads.  Measured faster than 256-row tiles at one
-    // workgroup per CU on every SD1.5 shape with this 2-stage pipeline (tools/kbench A/B).
+    const bool geglu = a.epi == EPI_GEGLU;
+    const bool n320 = !geglu && a.N % 320 == 0, n256 = a.N % 256 == 0;
+    int want256 = 0;
+    if (n320 || n256) {
+        const int bnb = n320 ? 320 : 256;
+        const long tiles = (long)((a.M + 255) / 256) * (a.N / bnb);
+        want256 = tiles >= 256;
+    }
+    if (g_force_bm == 128) want256 = 0;                       // development override (kbench A/B)
+    if (g_force_bm == 256) want256 = (n320 || n256);
+    if (want256) { *bm = 256; *bn = n320 ? 320 : 256; return; }
     *bm = 128;
-    if (g_force_bm == 128 || g_force_bm == 256) *bm = g_force_bm;     // development override (kbench A/B)
+    *bn = (a.N % 160 == 0 && !geglu) ? 160 : 128;
 }
 
 namespace {
@@ -92,24 +101,29 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 
 // LDS: two staging buffers for the K loop; the epilogue's four wave-private transpose slabs reuse them
-template <typename T, int BM, int BN, bool GEGLU, int NW, int NST>
+template <typename T, int BM, int BN, bool GEGLU, int WM, int WN, int NST>
 constexpr int gemm_lds_bytes() {
     const int stages = NST * (BM + BN) * 128;
-    const int epi = NW * 32 * ((GEGLU ? BN / 2 : BN) * (int)sizeof(T) + 16);
+    const int epi = WM * WN * 32 * ((GEGLU ? BN / WN / 2 : BN / WN) * (int)sizeof(T) + 16);
     return stages > epi ? stages : epi;
 }
 
-// NW waves stacked along M (each owns BM/NW rows x BN columns); NST LDS stages:
+// WM x WN waves; each owns a (BM/WM) x (BN/WN) sub-tile, so an A fragment is reused by BN/WN/32 MFMAs and
+// a B fragment by BM/WM/32: with 64 x 160 per wave the LDS read traffic per MFMA is 0.7 fragments
+// against 1.2 for 32 x 160 (the 4x1 layout) -- the LDS port, not the MFMA pipe, was the limiter there.
+// NST LDS stages:
 //   NST == 2: stage t+1 is issued at the top of step t and drained (vmcnt(0)) at its end;
 //   NST == 3: stage t+2 is issued at the top of step t and only stage t+1 -- a counted vmcnt --
 //             must have landed before the step's barrier, so a whole K tile of loads stays in
 //             flight across every barrier (raw s_barrier: __syncthreads() would drain the DMA).
-template <typename T, int BM, int BN, int MODE, bool GEGLU, int NW, int NST>
-__global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const GemmArgs p, const int tilesN) {
+template <typename T, int BM, int BN, int MODE, bool GEGLU, int WM, int WN, int NST>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p, const int tilesN) {
+    constexpr int NW = WM * WN;
     constexpr int BK = Traits<T>::BK;
     constexpr int KSUB = Traits<T>::KSUB;
     constexpr int VEC = Traits<T>::VEC;
-    constexpr int TM = BM / (NW * 32), TN = BN / 32;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int WBN = BN / WN;                           // columns per wave
     constexpr int NA = BM / (NW * 8);                      // 8-row DMA pieces of A per wave per stage
     constexpr int NBP = BN / 8;                            // 8-row DMA pieces of B per stage (all waves)
     constexpr int NB = (NBP + NW - 1) / NW;                // ... per wave (the last one may be partial)
@@ -223,13 +237,14 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const GemmArgs p, cons
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int nk = p.K / BK;
+    const int wm = wave / WN, wn = wave - wm * WN;
     const int half = lane >> 5;
     const int sw = (lane >> 1) & 7;                  // == (row>>1)&7 for row = 32*x + (lane&31)
     const int frow = (lane & 31) * 128;
 
     auto compute = [&](int buf) {
-        const char* sa = smem + buf * STAGE + wave * (BM / NW) * 128 + frow;
-        const char* sb = smem + buf * STAGE + A_BYTES + frow;
+        const char* sa = smem + buf * STAGE + wm * (BM / WM) * 128 + frow;
+        const char* sb = smem + buf * STAGE + A_BYTES + wn * WBN * 128 + frow;
         // fragments are register double-buffered: the ds_reads of step kk+1 are in flight while the
         // MFMAs of step kk run, so only the first read of a K tile exposes LDS latency
         Frag fa[2][TM], fb[2][TN];
@@ -294,13 +309,14 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const GemmArgs p, cons
     // through a private LDS region (the K loop's last barrier freed the staging buffers), then
     // streams it out row-contiguously: 16-byte coalesced residual loads and stores.
     constexpr int ES = sizeof(T);
-    constexpr int OUTW = GEGLU ? BN / 2 : BN;
+    constexpr int OUTW = GEGLU ? WBN / 2 : WBN;        // output columns this wave produces
     constexpr int RSO = OUTW * ES + 16;                 // staging row stride (bytes)
     constexpr int CPR = OUTW * ES / 16;                 // 16-byte chunks per output row
     char* const wst = smem + wave * (32 * RSO);
     T* const out = (T*)p.out;
     const T* const res = (const T*)p.residual;
-    const int nout0 = GEGLU ? (n0 >> 1) : n0;
+    const int nw0 = n0 + wn * WBN;                     // first packed weight row of this wave
+    const int nout0 = GEGLU ? (nw0 >> 1) : nw0;
     const int Nout = GEGLU ? (p.N >> 1) : p.N;
     const int l31 = lane & 31;
 #pragma unroll
@@ -313,7 +329,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const GemmArgs p, cons
                 float v[4];
                 if (GEGLU) {
                     // packed weight rows alternate 32-row blocks [h-block, g-block]
-                    const int nh = n0 + j * 32 + 8 * g + 4 * half;
+                    const int nh = nw0 + j * 32 + 8 * g + 4 * half;
                     f32x4 bh = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
                     if (p.bias && nh < p.N) {
                         bh = *reinterpret_cast<const f32x4*>(p.bias + nh);
@@ -340,7 +356,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const GemmArgs p, cons
             }
         }
         // read-back phase (same wave: LDS operations of one wave execute in order)
-        const int mrow0 = m0 + wave * (BM / NW) + i * 32;
+        const int mrow0 = m0 + wm * (BM / WM) + i * 32;
         for (int idx = lane; idx < 32 * CPR; idx += 64) {
             const int row = idx / CPR, c = idx - row * CPR;
             const int m = mrow0 + row, ncol = c * VEC;
@@ -389,12 +405,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_kernel(const GemmArgs p, cons
     }
 }
 
-template <typename T, int BM, int BN, int MODE, bool GEGLU, int NW = 4, int NST = 2>
+template <typename T, int BM, int BN, int MODE, bool GEGLU, int WM = 4, int WN = 1, int NST = 2>
 int launch_one(const GemmArgs& a, hipStream_t s) {
-    constexpr int LDS = gemm_lds_bytes<T, BM, BN, GEGLU, NW, NST>();
+    constexpr int NW = WM * WN;
+    constexpr int LDS = gemm_lds_bytes<T, BM, BN, GEGLU, WM, WN, NST>();
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_done = false;   // one handle per device / one host thread per handle
-    auto kern = gemm_kernel<T, BM, BN, MODE, GEGLU, NW, NST>;
+    auto kern = gemm_kernel<T, BM, BN, MODE, GEGLU, WM, WN, NST>;
     if (!attr_done) {
         DSIM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_done = true;
@@ -438,15 +455,16 @@ int launch_typed(const GemmArgs& a, hipStream_t s) {
     int bm, bn;
     gemm_tile_choice(a, &bm, &bn);
     const bool big = bm == 256, n160 = bn == 160;
+    (void)big;
     if constexpr (sizeof(T) == 2) {
-        // bf16, 256-row tiles: 8 waves, 3-stage LDS ring with a K tile of loads in flight across barriers
+        // bf16, big problems: 256-row tiles, 8 waves as 4(M) x 2(N), 64-row x (BN/2)-column sub-tiles
         if (big) {
-            if (a.epi == EPI_GEGLU) return launch_one<T, 256, 128, GEMM_LINEAR, true, 8, 3>(a, s);
+            if (a.epi == EPI_GEGLU) return launch_one<T, 256, 256, GEMM_LINEAR, true, 4, 2>(a, s);
             if (a.mode == GEMM_CONV3)
-                return n160 ? launch_one<T, 256, 160, GEMM_CONV3, false, 8, 3>(a, s)
-                            : launch_one<T, 256, 128, GEMM_CONV3, false, 8, 3>(a, s);
-            return n160 ? launch_one<T, 256, 160, GEMM_LINEAR, false, 8, 3>(a, s)
-                        : launch_one<T, 256, 128, GEMM_LINEAR, false, 8, 3>(a, s);
+                return bn == 320 ? launch_one<T, 256, 320, GEMM_CONV3, false, 4, 2>(a, s)
+                                 : launch_one<T, 256, 256, GEMM_CONV3, false, 4, 2>(a, s);
+            return bn == 320 ? launch_one<T, 256, 320, GEMM_LINEAR, false, 4, 2>(a, s)
+                             : launch_one<T, 256, 256, GEMM_LINEAR, false, 4, 2>(a, s);
         }
     }
     if (a.epi == EPI_GEGLU) return launch_one<T, 128, 128, GEMM_LINEAR, true>(a, s);

@@ -40,7 +40,8 @@ def rocprof_name(fam: str) -> str:
         bm, bn = p[2].split("x")
         mode = "1" if p[3] == "conv3" else "0"
         geglu = "true" if fam.endswith("_geglu") else "false"
-        return f"gemm_kernel<{t}, {bm}, {bn}, {mode}, {geglu}>"
+        wn = "2" if bm == "256" else "1"          # 256-row tiles run 8 waves as 4x2, 128-row tiles 4x1
+        return f"gemm_kernel<{t}, {bm}, {bn}, {mode}, {geglu}, 4, {wn}, 2>"
     return fam
 
 

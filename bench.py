@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--pixels-in", action="store_true",
+                    help="secondary line: include the VAE encoder (512x512 pixels in HBM -> score); the headline "
+                         "metric is latents-in")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,8 +113,20 @@ def main():
     shape = (2 * bp, 2, eng.tokens, eng.heads * eng.head_dim)
     qkv = tuple(torch.empty(shape, dtype=dtype, device=dev) for _ in range(3))
 
+    if a.pixels_in:
+        from diffsim_amd.engine import VAEEncoder
+        vae = VAEEncoder(C.VAE_SD15, S.make_state_dict(C.VAE_SD15, seed=1), dtype, str(dev))
+        imgs = torch.cat([torch.cat(S.make_image_pair(rank * bp + i, 512)) for i in range(bp)]).to(dev)   # [2*bp,3,512,512]
+        eps = torch.cat([noise[0], noise[1]] * bp).to(dev)         # the two VAE-sample draws (reference order)
+
     def step():
-        q, k, v = eng.qkv(lat, nz, sa, sb, ctx, out=qkv)
+        if a.pixels_in:
+            mom = vae.moments(imgs)
+            mean, logvar = mom.chunk(2, dim=1)
+            z = (mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * eps) * 0.18215
+            q, k, v = eng.qkv(z.contiguous(), nz, sa, sb, ctx, out=qkv)
+        else:
+            q, k, v = eng.qkv(lat, nz, sa, sb, ctx, out=qkv)
         return pair_score(q, k, v, ia, ib, eng.heads, "cosine")
 
     def barrier():
@@ -144,7 +159,8 @@ def main():
         "value": round(pairs_per_s, 3), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * el / a.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": "DiffSim SD1.5, synthetic 512px pairs (latents-in), up_blocks[0] t=600 (t=401), cosine",
+        "config": {"workload": "DiffSim SD1.5, synthetic 512px pairs (%s), up_blocks[0] t=600 (t=401), cosine"
+                               % ("pixels-in incl. VAE encoder" if a.pixels_in else "latents-in"),
                    "pairs_per_step_per_gpu": bp, "gflop_per_pair": GFLOP_PER_PAIR, "parallelism": f"pairs sharded x{world}"},
         "whole_path_tflops_per_gpu": round(pairs_per_s / world * GFLOP_PER_PAIR / 1e3, 2),
         "score_sample": [round(float(x), 6) for x in scores[:4].float().cpu()],

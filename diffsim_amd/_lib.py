@@ -37,6 +37,14 @@ class UNetCfgC(C.Structure):
     ]
 
 
+class VAECfgC(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32), ("latent_channels", C.c_int32), ("n_levels", C.c_int32),
+        ("block_out_channels", C.c_int32 * MAX_LEVELS), ("layers_per_block", C.c_int32),
+        ("norm_num_groups", C.c_int32), ("compute_dtype", C.c_int32),
+    ]
+
+
 # every symbol include/diffsim_amd.h declares: (restype, argtypes)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SYMBOLS = {
@@ -55,6 +63,12 @@ SYMBOLS = {
     "dsim_unet_profile_count": (_i, [_vp]),
     "dsim_unet_profile_get": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)]),
+    "dsim_vae_create": (_i, [C.POINTER(VAECfgC), C.POINTER(_vp)]),
+    "dsim_vae_destroy": (None, [_vp]),
+    "dsim_vae_load_weight": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(C.c_int64), _i]),
+    "dsim_vae_finalize": (_i, [_vp, _vp]),
+    "dsim_vae_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "dsim_vae_encode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "dsim_pair_score_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "dsim_pair_score": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "dsim_op_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

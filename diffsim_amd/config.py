@@ -143,3 +143,65 @@ def skip_channel_plan(cfg: UNetConfig) -> List[int]:
         if i != len(ch) - 1:
             skips.append(ch[i])
     return skips
+
+
+@dataclass(frozen=True)
+class VAEConfig:
+    """Encoder half of diffusers' AutoencoderKL config (SD1.5 ``vae/config.json``)."""
+    in_channels: int = 3
+    latent_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    norm_num_groups: int = 32
+    scaling_factor: float = 0.18215
+
+
+VAE_SD15 = VAEConfig()
+VAE_TINY = VAEConfig(block_out_channels=(64, 128, 256, 256))
+
+
+def _vae_resnet(p: str, cin: int, cout: int, out: Dict[str, Tuple[int, ...]]):
+    out[p + "norm1.weight"] = (cin,)
+    out[p + "norm1.bias"] = (cin,)
+    out[p + "conv1.weight"] = (cout, cin, 3, 3)
+    out[p + "conv1.bias"] = (cout,)
+    out[p + "norm2.weight"] = (cout,)
+    out[p + "norm2.bias"] = (cout,)
+    out[p + "conv2.weight"] = (cout, cout, 3, 3)
+    out[p + "conv2.bias"] = (cout,)
+    if cin != cout:
+        out[p + "conv_shortcut.weight"] = (cout, cin, 1, 1)
+        out[p + "conv_shortcut.bias"] = (cout,)
+
+
+def vae_encoder_param_shapes(cfg: VAEConfig) -> Dict[str, Tuple[int, ...]]:
+    """Encoder + quant_conv parameters of AutoencoderKL under their diffusers keys."""
+    out: Dict[str, Tuple[int, ...]] = {}
+    ch = cfg.block_out_channels
+    out["encoder.conv_in.weight"] = (ch[0], cfg.in_channels, 3, 3)
+    out["encoder.conv_in.bias"] = (ch[0],)
+    prev = ch[0]
+    for i, c in enumerate(ch):
+        for j in range(cfg.layers_per_block):
+            _vae_resnet(f"encoder.down_blocks.{i}.resnets.{j}.", prev if j == 0 else c, c, out)
+        if i != len(ch) - 1:
+            out[f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"] = (c, c, 3, 3)
+            out[f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"] = (c,)
+        prev = c
+    c = ch[-1]
+    _vae_resnet("encoder.mid_block.resnets.0.", c, c, out)
+    a = "encoder.mid_block.attentions.0."
+    out[a + "group_norm.weight"] = (c,)
+    out[a + "group_norm.bias"] = (c,)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        out[a + n + ".weight"] = (c, c)
+        out[a + n + ".bias"] = (c,)
+    _vae_resnet("encoder.mid_block.resnets.1.", c, c, out)
+    out["encoder.conv_norm_out.weight"] = (c,)
+    out["encoder.conv_norm_out.bias"] = (c,)
+    m = 2 * cfg.latent_channels
+    out["encoder.conv_out.weight"] = (m, c, 3, 3)
+    out["encoder.conv_out.bias"] = (m,)
+    out["quant_conv.weight"] = (m, m, 1, 1)
+    out["quant_conv.bias"] = (m,)
+    return out

@@ -43,6 +43,7 @@ struct GemmArgs {
     int mode = GEMM_LINEAR;
     int Hin = 0, Win = 0, Hout = 0, Wout = 0;   // CONV3 geometry (Hin/Win = stored input size)
     int stride = 1, ups = 0;
+    int pad = 1;                                // 1: symmetric padding; 0: VAE downsample (pad right/bottom only)
     int M = 0, N = 0, K = 0;                    // N counts packed weight rows (2x out cols for GEGLU)
     const void* W = nullptr;                    // packed [N][K], compute dtype
     const float* bias = nullptr;                // [N] f32 (packed order) or null
@@ -73,8 +74,8 @@ int timestep_sincos(float* out, int dim, int t, hipStream_t s);
 
 // noising + CFG duplication + conv_in (direct) -- pack.hip
 //   x_t = sa*lat + sb*noise ; out[(img*2+cfg)][pix][co] for cfg in {0,1}
-int prep_conv_in(const float* lat, const float* noise, float sa, float sb, const float* w /*[36][Cout]*/,
-                 const float* bias, void* out, int dtype, int n_img, int Cin, int S, int Cout,
+int prep_conv_in(const float* lat, const float* noise /*nullable*/, float sa, float sb, const float* w /*[9*Cin][Cout]*/,
+                 const float* bias, void* out, int dtype, int n_img, int Cin, int S, int Cout, int dup /*1|2*/,
                  hipStream_t st);
 int convert_f32_to(const float* src, void* dst, int dtype, size_t n, hipStream_t s);
 
@@ -85,6 +86,8 @@ int launch_groupnorm(const void* x0, int C0, const void* x1, int C1, const float
                      int dtype, void* scratch, hipStream_t s);
 int launch_layernorm(const void* x, const float* gamma, const float* beta, void* out, int M, int C,
                      float eps, int dtype, hipStream_t s);
+// out[r][:] = softmax(x[r][:] * scale) over `cols` (VAE mid-block attention; in place allowed)
+int launch_softmax_rows(const void* x, void* out, int rows, int cols, float scale, int dtype, hipStream_t s);
 
 // attention + fused score tail -- attention.hip
 struct AttnArgs {

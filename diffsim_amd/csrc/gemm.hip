@@ -164,8 +164,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
             const int hw = p.Hout * p.Wout;
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-            a_iy0[i] = (m < p.M) ? oy * p.stride - 1 : -(1 << 20);
-            a_ix0[i] = ox * p.stride - 1;
+            a_iy0[i] = (m < p.M) ? oy * p.stride - p.pad : -(1 << 20);
+            a_ix0[i] = ox * p.stride - p.pad;
             a_base[i] = (unsigned)b * (unsigned)(p.Hin * p.Win);
             a_voff[i] = OOB;
         } else {

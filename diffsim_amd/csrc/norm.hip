@@ -239,6 +239,52 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+
+// softmax over rows of `cols` elements (one 256-thread workgroup per row; cols % VEC == 0).  Used by
+// the VAE encoder's single-head 512-d mid-block attention, whose score matrix is materialised by
+// the GEMM kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__ x, T* __restrict__ out, int cols,
+                                                           float scale_log2) {
+    constexpr int VEC = Vec16<T>::N;
+    typedef typename Vec16<T>::type V;
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* xr = x + (size_t)blockIdx.x * cols;
+    T* orow = out + (size_t)blockIdx.x * cols;
+    const int S = cols / VEC;
+    float m = -INFINITY;
+    for (int s = tid; s < S; s += 256) {
+        const V v = *reinterpret_cast<const V*>(xr + s * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) m = fmaxf(m, (float)v[e]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float mb = m * scale_log2;
+    float sum = 0.f;
+    for (int s = tid; s < S; s += 256) {
+        const V v = *reinterpret_cast<const V*>(xr + s * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sum += exp2f(fmaf((float)v[e], scale_log2, -mb));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    for (int s = tid; s < S; s += 256) {
+        const V v = *reinterpret_cast<const V*>(xr + s * VEC);
+        V o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = (T)(exp2f(fmaf((float)v[e], scale_log2, -mb)) * inv);
+        *reinterpret_cast<V*>(orow + s * VEC) = o;
+    }
+}
+
 template <typename T>
 int gn_typed(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta,
              void* out, int B, int HW, int groups, float eps, int silu, void* scratch, hipStream_t s) {
@@ -290,6 +336,20 @@ int launch_layernorm(const void* x, const float* gamma, const float* beta, void*
         hipLaunchKernelGGL(layernorm_kernel<bf16>, grid, block, 0, s, (const bf16*)x, gamma, beta, (bf16*)out, M, C, eps);
     else if (dtype == DSIM_F32)
         hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, s, (const float*)x, gamma, beta, (float*)out, M, C, eps);
+    else
+        return DSIM_ERR_INVALID;
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+
+int launch_softmax_rows(const void* x, void* out, int rows, int cols, float scale, int dtype, hipStream_t s) {
+    const int vec = dtype == DSIM_F32 ? 4 : 8;
+    if (cols % vec || rows < 1) return DSIM_ERR_INVALID;
+    const float sl2 = scale * 1.4426950408889634f;
+    if (dtype == DSIM_BF16)
+        hipLaunchKernelGGL(softmax_rows_kernel<bf16>, dim3(rows), dim3(256), 0, s, (const bf16*)x, (bf16*)out, cols, sl2);
+    else if (dtype == DSIM_F32)
+        hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)x, (float*)out, cols, sl2);
     else
         return DSIM_ERR_INVALID;
     DSIM_HIP_CHECK(hipGetLastError());

@@ -98,7 +98,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void prep_conv_in_kernel(const float* __restrict__ lat, const float* __restrict__ noise,
                                                            float sa, float sb, const float* __restrict__ w,
                                                            const float* __restrict__ bias, T* __restrict__ out, int Cin,
-                                                           int S, int Cout) {
+                                                           int S, int Cout, int dup) {
     extern __shared__ float patch[];                // [PREP_PIX][9*Cin]
     const int img = blockIdx.y, p0 = blockIdx.x * PREP_PIX, K = 9 * Cin, HW = S * S;
     for (int i = threadIdx.x; i < PREP_PIX * K; i += 256) {
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void prep_conv_in_kernel(const float* __restri
             const int y = pix / S + tap / 3 - 1, x = pix % S + tap % 3 - 1;
             if ((unsigned)y < (unsigned)S && (unsigned)x < (unsigned)S) {
                 const size_t o = (((size_t)img * Cin + ci) * S + y) * S + x;
-                v = sa * lat[o] + sb * noise[o];
+                v = noise ? sa * lat[o] + sb * noise[o] : lat[o];
             }
         }
         patch[i] = v;
@@ -131,8 +131,7 @@ __global__ __launch_bounds__(256) void prep_conv_in_kernel(const float* __restri
             const int pix = p0 + pp;
             if (pix < HW) {
                 const T v = (T)acc[pp];
-                out[((size_t)(img * 2 + 0) * HW + pix) * Cout + co] = v;
-                out[((size_t)(img * 2 + 1) * HW + pix) * Cout + co] = v;
+                for (int d = 0; d < dup; ++d) out[((size_t)(img * dup + d) * HW + pix) * Cout + co] = v;
             }
         }
     }
@@ -186,13 +185,13 @@ int timestep_sincos(float* out, int dim, int t, hipStream_t s) {
     return DSIM_OK;
 }
 int prep_conv_in(const float* lat, const float* noise, float sa, float sb, const float* w, const float* bias, void* out,
-                 int dtype, int n_img, int Cin, int S, int Cout, hipStream_t st) {
+                 int dtype, int n_img, int Cin, int S, int Cout, int dup, hipStream_t st) {
     const dim3 grid((S * S + PREP_PIX - 1) / PREP_PIX, n_img), block(256);
     const size_t lds = (size_t)PREP_PIX * 9 * Cin * sizeof(float);
     if (dtype == DSIM_BF16)
-        hipLaunchKernelGGL(prep_conv_in_kernel<bf16>, grid, block, lds, st, lat, noise, sa, sb, w, bias, (bf16*)out, Cin, S, Cout);
+        hipLaunchKernelGGL(prep_conv_in_kernel<bf16>, grid, block, lds, st, lat, noise, sa, sb, w, bias, (bf16*)out, Cin, S, Cout, dup);
     else if (dtype == DSIM_F32)
-        hipLaunchKernelGGL(prep_conv_in_kernel<float>, grid, block, lds, st, lat, noise, sa, sb, w, bias, (float*)out, Cin, S, Cout);
+        hipLaunchKernelGGL(prep_conv_in_kernel<float>, grid, block, lds, st, lat, noise, sa, sb, w, bias, (float*)out, Cin, S, Cout, dup);
     else
         return DSIM_ERR_INVALID;
     DSIM_HIP_CHECK(hipGetLastError());

@@ -239,3 +239,102 @@ def op_attention(q, k, v, heads):
     _lib.check(L.dsim_op_attention(q.data_ptr(), HD, k.data_ptr(), v.data_ptr(), HD, out.data_ptr(), HD, B, Bkv, heads,
                                    Nq, Nk, HD // heads, _TORCH2DSIM[q.dtype], _stream_ptr()), "op_attention")
     return out
+
+
+# ---- VAE encoder ------------------------------------------------------------
+class _LatentDist:
+    """``DiagonalGaussianDistribution`` surface the reference uses: ``.sample(generator)``
+    (diffsim/diffsim.py:94).  mean/logvar live on the device; the noise is drawn with the caller's
+    generator on ITS device (CPU in the reference-CPU-path setting) in the reference's order."""
+
+    def __init__(self, moments: torch.Tensor):
+        self.mean, logvar = moments.chunk(2, dim=1)
+        self.logvar = logvar.clamp(-30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, generator=None) -> torch.Tensor:
+        gdev = generator.device if generator is not None else self.mean.device
+        eps = torch.randn(self.mean.shape, generator=generator, dtype=torch.float32, device=gdev)
+        return self.mean + self.std * eps.to(self.mean.device)
+
+    def mode(self) -> torch.Tensor:
+        return self.mean
+
+
+class _EncodeOut:
+    def __init__(self, moments):
+        self.latent_dist = _LatentDist(moments)
+
+
+class VAEEncoder:
+    """``AutoencoderKL.encode`` on the HIP engine, with the surface DiffSim.prepare_image_latents needs:
+    ``vae.encode(image).latent_dist.sample(generator)`` and ``vae.config.scaling_factor``."""
+
+    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], dtype: torch.dtype = torch.bfloat16,
+                 device: str = "cuda:0"):
+        import types
+        self.L = _lib.lib()
+        if not torch.cuda.is_available():
+            raise _lib.DsimError("no GPU visible: the VAE encoder runs only on the HIP device")
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self.config = types.SimpleNamespace(scaling_factor=cfg.scaling_factor)
+        c = _lib.VAECfgC()
+        c.in_channels, c.latent_channels, c.n_levels = cfg.in_channels, cfg.latent_channels, len(cfg.block_out_channels)
+        for i, v in enumerate(cfg.block_out_channels):
+            c.block_out_channels[i] = v
+        c.layers_per_block, c.norm_num_groups = cfg.layers_per_block, cfg.norm_num_groups
+        c.compute_dtype = _TORCH2DSIM[dtype]
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.dsim_vae_create(C.byref(c), C.byref(self._h)), "dsim_vae_create")
+            keep = []
+            for k, v in state_dict.items():
+                if not (k.startswith("encoder.") or k.startswith("quant_conv.")):
+                    continue
+                t = v.detach()
+                if t.dtype not in _TORCH2DSIM:
+                    t = t.float()
+                t = t.to(self.device).contiguous()
+                keep.append(t)
+                shp = (C.c_int64 * t.ndim)(*t.shape)
+                _lib.check(self.L.dsim_vae_load_weight(self._h, k.encode(), t.data_ptr(), _TORCH2DSIM[t.dtype], shp, t.ndim),
+                           f"vae load_weight({k})")
+            torch.cuda.synchronize(self.device)
+            _lib.check(self.L.dsim_vae_finalize(self._h, _stream_ptr()), "dsim_vae_finalize")
+            del keep
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self.L.dsim_vae_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def moments(self, images: torch.Tensor) -> torch.Tensor:
+        """images (n,3,S,S) in [-1,1], any float dtype/device -> moments (n, 2*latent, S/8, S/8) f32 on device."""
+        x = images.to(self.device).float().contiguous()      # an fp16 image keeps its fp16-rounded pixel values
+        n, cin, S, S2 = x.shape
+        if cin != self.cfg.in_channels or S != S2:
+            raise _lib.DsimError("images must be (n, in_channels, S, S)")
+        f = 2 ** (len(self.cfg.block_out_channels) - 1)
+        out = torch.empty((n, 2 * self.cfg.latent_channels, S // f, S // f), dtype=torch.float32, device=self.device)
+        # the kernels address activations through 32-bit buffer offsets: keep every tensor < 2 GiB
+        es = 4 if self.dtype == torch.float32 else 2
+        chunk = max(1, (2 ** 30) // (S * S * max(self.cfg.block_out_channels[0], 1) * es))
+        with torch.cuda.device(self.device):
+            for i0 in range(0, n, chunk):
+                m = min(chunk, n - i0)
+                need = int(self.L.dsim_vae_workspace_bytes(self._h, m, S))
+                if need == 0:
+                    raise _lib.DsimError("unsupported image size for the VAE encoder")
+                if self._ws is None or self._ws.numel() < need:
+                    self._ws = None
+                    self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                _lib.check(self.L.dsim_vae_encode(self._h, x[i0:i0 + m].data_ptr(), m, S, out[i0:i0 + m].data_ptr(),
+                                                  self._ws.data_ptr(), self._ws.numel(), _stream_ptr()), "dsim_vae_encode")
+        return out
+
+    def encode(self, images: torch.Tensor) -> _EncodeOut:
+        return _EncodeOut(self.moments(images))

@@ -1,0 +1,125 @@
+"""Triplet / 2AFC benchmark harness with a per-(image, slot) feature cache.
+
+The reference's drivers score every triplet with two full scorer calls, (A,B) and (A,C)
+(``cute_main.py:111-132``, ``night_main.py:69-163``): image A is encoded, noised and pushed through
+the U-Net twice with identical seed and slot, i.e. to bit-identical features.  Here the reference
+image's features are computed once and shared by both pairs (3 U-Net forwards per triplet instead
+of 4), every triplet of a chunk runs in one engine batch, and both scores of every triplet come
+out of one fused tail launch (``dsim_pair_score`` takes index pairs into the feature tensor).
+
+Decision rules mirror the reference:
+  NIGHTS 2AFC  ``night_main.py:156-163``  cosine: predicted = 1 if s(ref,left) > s(ref,right) else 0;
+                                          mse:    predicted = 1 if s(ref,left) < s(ref,right) else 0;
+                                          correct when predicted == int(row['left_vote'])
+  CUTE         ``cute_main.py:201-205``   correct when s(A,B) > s(A,C)  (B same instance, C other)
+"""
+from __future__ import annotations
+
+import csv
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from .diffsim import DiffSim, _norm_layer, get_generator
+from .engine import pair_score
+from .image import load_image, process_image
+from .parallel import gather_scores, shard_triplets
+
+
+@torch.no_grad()
+def score_latent_triplets(scorer: DiffSim, lat_ref: torch.Tensor, lat_left: torch.Tensor, lat_right: torch.Tensor,
+                          noiseA: torch.Tensor, noiseB: torch.Tensor, prompt, target_block="up_blocks", target_layer=0,
+                          target_step=600, similarity="cosine", batch_triplets: int = 10
+                          ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Scores (ref,left) and (ref,right) for every triplet; ref sits in slot A (noiseA), left and
+    right in slot B (noiseB) exactly as two reference calls would place them.  Returns two (n,) f32
+    device tensors that are bit-identical to 2n separate ``diffsim_latents`` calls."""
+    n = lat_ref.shape[0]
+    eng = scorer.engine(target_block, target_layer)
+    s_l = torch.empty(n, dtype=torch.float32, device=scorer.device)
+    s_r = torch.empty(n, dtype=torch.float32, device=scorer.device)
+    shp = lat_ref.shape[1:]
+    for i0 in range(0, n, batch_triplets):
+        i1 = min(n, i0 + batch_triplets)
+        m = i1 - i0
+        lat = torch.stack([lat_ref[i0:i1], lat_left[i0:i1], lat_right[i0:i1]], dim=1).reshape(3 * m, *shp)
+        nz = torch.stack([noiseA.expand(m, *shp), noiseB.expand(m, *shp), noiseB.expand(m, *shp)], dim=1).reshape(3 * m, *shp)
+        q, k, v = scorer.features(lat, nz, prompt, target_block, target_layer, target_step)
+        base = torch.arange(0, 3 * m, 3, dtype=torch.int32, device=scorer.device)
+        ia = torch.cat([base, base])
+        ib = torch.cat([base + 1, base + 2])
+        s = pair_score(q, k, v, ia, ib, eng.heads, similarity)
+        s_l[i0:i1], s_r[i0:i1] = s[:m], s[m:]
+    return s_l, s_r
+
+
+def read_nights_csv(image_path: str, split: str = "val") -> List[dict]:
+    """``data.csv`` of NIGHTS: split, ref_path, left_path, right_path, left_vote, prompt
+    (night_main.py:53-67)."""
+    rows = []
+    with open(os.path.join(image_path, "data.csv"), mode="r") as f:
+        for row in csv.DictReader(f):
+            if row["split"] != split:
+                continue
+            rows.append({"ref": os.path.join(image_path, row["ref_path"]), "left": os.path.join(image_path, row["left_path"]),
+                         "right": os.path.join(image_path, row["right_path"]), "vote": int(row["left_vote"]),
+                         "prompt": f"An image of a {row['prompt'].lower()}"})
+    return rows
+
+
+def nights_decisions(s_left: torch.Tensor, s_right: torch.Tensor, similarity: str) -> torch.Tensor:
+    if similarity == "mse":
+        return (s_left < s_right).to(torch.int64)
+    return (s_left > s_right).to(torch.int64)
+
+
+def nights_accuracy(s_left, s_right, votes: Sequence[int], similarity: str = "cosine") -> float:
+    pred = nights_decisions(s_left.cpu(), s_right.cpu(), similarity)
+    v = torch.tensor(list(votes), dtype=torch.int64)
+    return float((pred == v).float().mean() * 100.0) if len(v) else 0.0
+
+
+def cute_accuracy(s_ab: torch.Tensor, s_ac: torch.Tensor) -> float:
+    return float((s_ab.cpu() > s_ac.cpu()).float().mean() * 100.0) if s_ab.numel() else 0.0
+
+
+@torch.no_grad()
+def nights_eval(scorer: DiffSim, image_path: str, img_size: int, target_block, target_layer, target_step, seed=2333,
+                similarity="cosine", rank: int = 0, world: int = 1, batch_triplets: int = 10) -> float:
+    """The whole night_main.py loop, triplets sharded over ranks (whole triplets per rank so the
+    cached reference features stay local), scores gathered with one all_gather per side."""
+    rows = read_nights_csv(image_path)
+    mine = shard_triplets(len(rows), rank, world)
+    layer = _norm_layer(target_layer)
+    sl, sr = [], []
+    # prompts differ per row: group the shard by prompt so each context is encoded once
+    by_prompt = {}
+    for j in mine:
+        by_prompt.setdefault(rows[j]["prompt"], []).append(j)
+    order, nA, nB = [], None, None
+    for prompt, idxs in by_prompt.items():
+        ref, left, right = [], [], []
+        for j in idxs:
+            # one generator per (ref,left) call; (ref,right) reproduces the same ref/noise draws
+            g = get_generator(seed, "cpu")
+            a = scorer.prepare_image_latents(process_image(load_image(rows[j]["ref"]), img_size), None, None, g)
+            b = scorer.prepare_image_latents(process_image(load_image(rows[j]["left"]), img_size), None, None, g)
+            if nA is None:
+                nA = torch.randn(a.shape, generator=g, dtype=torch.float32)
+                nB = torch.randn(a.shape, generator=g, dtype=torch.float32)
+            g2 = get_generator(seed, "cpu")
+            scorer.prepare_image_latents(process_image(load_image(rows[j]["ref"]), img_size), None, None, g2)
+            c = scorer.prepare_image_latents(process_image(load_image(rows[j]["right"]), img_size), None, None, g2)
+            ref.append(a.float()); left.append(b.float()); right.append(c.float())
+        a_, b_ = score_latent_triplets(scorer, torch.cat(ref), torch.cat(left), torch.cat(right), nA, nB, prompt,
+                                       target_block, layer, target_step, similarity, batch_triplets)
+        sl.append(a_); sr.append(b_); order += idxs
+    if order:
+        inv = torch.tensor(sorted(range(len(order)), key=lambda t: order[t]), dtype=torch.long, device=scorer.device)
+        loc_l, loc_r = torch.cat(sl)[inv], torch.cat(sr)[inv]
+    else:
+        loc_l = loc_r = torch.empty(0, dtype=torch.float32, device=scorer.device)
+    all_l = gather_scores(loc_l, len(rows), rank, world)
+    all_r = gather_scores(loc_r, len(rows), rank, world)
+    return nights_accuracy(all_l, all_r, [r["vote"] for r in rows], similarity)

@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from .config import UNetConfig, unet_param_shapes
+from .config import UNetConfig, VAEConfig, unet_param_shapes, vae_encoder_param_shapes
 
 
 def make_state_dict(cfg: UNetConfig, seed: int = 0, keys: Optional[Sequence[str]] = None
@@ -22,14 +22,14 @@ def make_state_dict(cfg: UNetConfig, seed: int = 0, keys: Optional[Sequence[str]
     1.4 so attention logits have std ~2 (non-degenerate softmax; SURVEY.md section 7 "hard parts");
     norm affine parameters are perturbed away from (1,0) so a dropped gamma/beta is caught.
     Each tensor has its own generator keyed by its position, so a subset is reproducible."""
-    shapes = unet_param_shapes(cfg)
+    shapes = vae_encoder_param_shapes(cfg) if isinstance(cfg, VAEConfig) else unet_param_shapes(cfg)
     out: Dict[str, torch.Tensor] = {}
     for idx, (k, shp) in enumerate(shapes.items()):
         if keys is not None and k not in keys:
             continue
         g = torch.Generator("cpu").manual_seed(seed * 1000003 + idx)
         leaf = k.rsplit(".", 2)
-        is_norm = ".norm" in k or k.startswith("conv_norm_out")
+        is_norm = ".norm" in k or "conv_norm_out" in k or "group_norm" in k
         if is_norm and k.endswith(".weight"):
             t = 1.0 + 0.1 * torch.randn(shp, generator=g)
         elif is_norm and k.endswith(".bias"):
@@ -81,3 +81,16 @@ def draw_pair_noise(seed: int, shape: Sequence[int]) -> List[torch.Tensor]:
     (reference: diffsim/diffsim.py:109-113 and diffsim/diffsim_pipeline.py:174-176)."""
     g = torch.Generator("cpu").manual_seed(int(seed))
     return [torch.randn(tuple(shape), generator=g, dtype=torch.float32) for _ in range(4)]
+
+
+def make_image_pair(pair_index: int, size: int = 512, base_seed: int = 1234) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Pixels-in synthetic pair i: uint8-quantised ``0.5*noise + 0.5*lowfreq``
+    images, returned as process_image-style (1,3,S,S) f32 tensors in [-1,1]; image A drawn first."""
+    g = torch.Generator("cpu").manual_seed(base_seed + pair_index)
+    outs = []
+    for _ in range(2):
+        hf = torch.randint(0, 256, (1, 3, size, size), generator=g).float()
+        lf = _lowfreq(g, 3, size, normal=False) * 255.0
+        img = torch.round(0.5 * hf + 0.5 * lf).clamp(0, 255) / 255.0
+        outs.append((img - 0.5) / 0.5)
+    return outs[0], outs[1]

@@ -133,6 +133,33 @@ int    dsim_pair_score(const void* q, const void* k, const void* v, const int32_
                        int similarity, float* out_scores, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* ---- VAE encoder: replaces `pipe.vae.encode(image)` in
+ *      DiffSim.prepare_image_latents (diffsim/diffsim.py:92-96).  Sampling
+ *      z = mean + exp(0.5*clamp(logvar,-30,20))*eps and the 0.18215 scaling stay with the caller,
+ *      which owns the generator whose draw order defines the score. ------------------------------ */
+typedef struct dsim_vae_cfg {
+    int32_t in_channels;                          /* 3 */
+    int32_t latent_channels;                      /* 4 */
+    int32_t n_levels;                             /* 4 */
+    int32_t block_out_channels[DSIM_MAX_LEVELS];  /* 128,256,512,512 */
+    int32_t layers_per_block;                     /* 2 */
+    int32_t norm_num_groups;                      /* 32 */
+    int32_t compute_dtype;                        /* DSIM_F32 or DSIM_BF16 */
+} dsim_vae_cfg;
+typedef struct dsim_vae dsim_vae;
+
+int    dsim_vae_create(const dsim_vae_cfg* cfg, dsim_vae** out);
+void   dsim_vae_destroy(dsim_vae* h);
+/* diffusers AutoencoderKL keys: "encoder.*" and "quant_conv.*" (decoder keys are not needed) */
+int    dsim_vae_load_weight(dsim_vae* h, const char* key, const void* dev_ptr, int dtype,
+                            const int64_t* shape, int ndim);
+int    dsim_vae_finalize(dsim_vae* h, void* stream);
+size_t dsim_vae_workspace_bytes(const dsim_vae* h, int n_images, int image_size);
+/* images: f32 [n][3][S][S] in [-1,1] (process_image output); moments (out): f32 [n][2*latent][S/8][S/8]
+ * = cat(mean, logvar) exactly as AutoencoderKL's quant_conv output */
+int    dsim_vae_encode(dsim_vae* h, const float* images, int n_images, int image_size, float* moments,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- single-operator entry points (kernel-level parity tests and micro-benchmarks) -----
  * x: dtype [M][K] (or NHWC image for the conv forms); w: diffusers-layout f32 weight.      */
 int dsim_op_linear(const void* x, const float* w /*[N][K]*/, const float* bias /*[N] or NULL*/,

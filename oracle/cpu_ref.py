@@ -598,3 +598,132 @@ def build_unet(cfg: UNetConfig, state_dict: dict) -> UNet2DConditionModel:
     m = UNet2DConditionModel(cfg)
     m.load_state_dict({k: v.float() for k, v in state_dict.items()}, strict=True)
     return m.eval()
+
+
+# ----------------------------------------------------------------------------------------------
+# VAE encoder (reference call site diffsim/diffsim.py:92-96:
+# ``pipe.vae.encode(image).latent_dist.sample(generator) * scaling_factor``).  diffusers'
+# AutoencoderKL is not vendored: restated from SURVEY.md Appendix A item 11 -- PARITY UNPINNED.
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class VAEConfig:
+    in_channels: int = 3
+    latent_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    norm_num_groups: int = 32
+    scaling_factor: float = 0.18215
+
+
+VAE_SD15 = VAEConfig()
+VAE_TINY = VAEConfig(block_out_channels=(64, 128, 256, 256))
+
+
+class VAEResnet(nn.Module):
+    def __init__(self, cin, cout, groups):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, cin, eps=1e-6)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.norm2 = nn.GroupNorm(groups, cout, eps=1e-6)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+
+    def forward(self, x):
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = self.conv2(F.silu(self.norm2(h)))
+        return (self.conv_shortcut(x) if self.conv_shortcut is not None else x) + h
+
+
+class VAEDownsample(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, stride=2, padding=0)
+
+    def forward(self, x):
+        return self.conv(F.pad(x, (0, 1, 0, 1), mode="constant", value=0))
+
+
+class VAEDownBlock(nn.Module):
+    def __init__(self, cin, cout, n, groups, down):
+        super().__init__()
+        self.resnets = nn.ModuleList([VAEResnet(cin if i == 0 else cout, cout, groups) for i in range(n)])
+        self.downsamplers = nn.ModuleList([VAEDownsample(cout)]) if down else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x)
+        return x
+
+
+class VAEAttention(nn.Module):
+    """single-head spatial self-attention with GroupNorm and a residual connection"""
+
+    def __init__(self, c, groups):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(groups, c, eps=1e-6)
+        self.to_q = nn.Linear(c, c)
+        self.to_k = nn.Linear(c, c)
+        self.to_v = nn.Linear(c, c)
+        self.to_out = nn.ModuleList([nn.Linear(c, c), nn.Dropout(0.0)])
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        t = self.group_norm(x).view(b, c, h * w).transpose(1, 2)
+        q, k, v = self.to_q(t), self.to_k(t), self.to_v(t)
+        o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
+        o = self.to_out[0](o).transpose(1, 2).reshape(b, c, h, w)
+        return o + x
+
+
+class VAEMidBlock(nn.Module):
+    def __init__(self, c, groups):
+        super().__init__()
+        self.resnets = nn.ModuleList([VAEResnet(c, c, groups), VAEResnet(c, c, groups)])
+        self.attentions = nn.ModuleList([VAEAttention(c, groups)])
+
+    def forward(self, x):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x)))
+
+
+class VAEEncoderNet(nn.Module):
+    def __init__(self, cfg: VAEConfig):
+        super().__init__()
+        ch = cfg.block_out_channels
+        self.conv_in = nn.Conv2d(cfg.in_channels, ch[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        prev = ch[0]
+        for i, c in enumerate(ch):
+            self.down_blocks.append(VAEDownBlock(prev, c, cfg.layers_per_block, cfg.norm_num_groups, i != len(ch) - 1))
+            prev = c
+        self.mid_block = VAEMidBlock(ch[-1], cfg.norm_num_groups)
+        self.conv_norm_out = nn.GroupNorm(cfg.norm_num_groups, ch[-1], eps=1e-6)
+        self.conv_out = nn.Conv2d(ch[-1], 2 * cfg.latent_channels, 3, padding=1)
+
+    def forward(self, x):
+        x = self.conv_in(x)
+        for b in self.down_blocks:
+            x = b(x)
+        x = self.mid_block(x)
+        return self.conv_out(F.silu(self.conv_norm_out(x)))
+
+
+class AutoencoderKLEncoder(nn.Module):
+    """encode(x) -> moments (mean, logvar); sample = mean + exp(0.5*clamp(logvar,-30,20)) * randn(generator)"""
+
+    def __init__(self, cfg: VAEConfig = VAE_SD15):
+        super().__init__()
+        self.cfg = cfg
+        self.encoder = VAEEncoderNet(cfg)
+        self.quant_conv = nn.Conv2d(2 * cfg.latent_channels, 2 * cfg.latent_channels, 1)
+
+    @torch.no_grad()
+    def moments(self, x):
+        return self.quant_conv(self.encoder(x.float()))
+
+    @torch.no_grad()
+    def sample(self, x, generator=None):
+        mean, logvar = self.moments(x).chunk(2, dim=1)
+        std = torch.exp(0.5 * logvar.clamp(-30.0, 20.0))
+        return mean + std * torch.randn(mean.shape, generator=generator, dtype=mean.dtype)

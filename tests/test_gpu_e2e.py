@@ -172,3 +172,43 @@ def test_errors_are_loud(tiny_env, golden_dir):
     with pytest.raises(_lib.DsimError):
         from diffsim_amd.engine import UNetEngine
         UNetEngine(C.TINY, {"conv_in.weight": tiny_env["sd"]["conv_in.weight"]}, torch.float32)   # missing weights
+
+
+def test_triplet_harness_matches_pairwise_calls(tiny_env, golden_dir, tmp_path):
+    """NIGHTS-shaped 2AFC run (config 3 shape): cached-reference triplet scoring must reproduce,
+    bit for bit, the two separate scorer calls per triplet the reference driver makes
+    (night_main.py:69-163), and the accuracy rule must match."""
+    import csv
+    import shutil
+    from diffsim_amd import harness as Hn
+    from tests._fakes import FakeVAE
+    ctx = tiny_env["ctx"]
+    ds = _scorer(C.TINY, tiny_env["sd"], torch.float32, vae=FakeVAE(), encode_prompt=lambda p: ctx)
+    names = ["g1_img_a.png", "g1_img_b.png", "g1_img_c.png", "g1_img_d.png"]
+    for n in names:
+        shutil.copy(os.path.join(golden_dir, n), tmp_path / n)
+    rows = [("val", names[0], names[1], names[2], 1, "Cat"), ("train", names[1], names[2], names[3], 0, "Dog"),
+            ("val", names[3], names[0], names[1], 0, "Dog"), ("val", names[2], names[3], names[0], 1, "Cat")]
+    with open(tmp_path / "data.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["split", "ref_path", "left_path", "right_path", "left_vote", "prompt"])
+        w.writerows(rows)
+    parsed = Hn.read_nights_csv(str(tmp_path))
+    assert len(parsed) == 3 and parsed[0]["prompt"] == "An image of a cat"
+    for sim in ("cosine", "mse"):
+        acc = Hn.nights_eval(ds, str(tmp_path), 128, "up_blocks", [0], 600, seed=2334, similarity=sim)
+        correct = 0
+        for r in parsed:
+            ab = ds.diffsim(r["ref"], r["left"], 128, r["prompt"], "up_blocks", [0], 600, seed=2334, similarity=sim)
+            ac = ds.diffsim(r["ref"], r["right"], 128, r["prompt"], "up_blocks", [0], 600, seed=2334, similarity=sim)
+            pred = (1 if ab < ac else 0) if sim == "mse" else (1 if ab > ac else 0)
+            correct += int(pred == r["vote"])
+        assert abs(acc - 100.0 * correct / len(parsed)) < 1e-3
+    # bit-exact equality of cached-reference scores with the pairwise path
+    lat = [S.make_pair_latents(C.TINY, i) for i in range(3)]
+    ref = torch.cat([p[0] for p in lat]); left = torch.cat([p[1] for p in lat]); right = torch.cat([p[0] for p in lat[::-1]])
+    n = S.draw_pair_noise(2334, lat[0][0].shape)
+    sl, sr = Hn.score_latent_triplets(ds, ref, left, right, n[2], n[3], ctx, batch_triplets=2)
+    pl = ds.score_latent_pairs(ref, left, n[2], n[3], ctx)
+    pr = ds.score_latent_pairs(ref, right, n[2], n[3], ctx)
+    assert torch.equal(sl, pl) and torch.equal(sr, pr)

@@ -108,3 +108,12 @@ def test_synthetic_inputs_are_deterministic():
     sd2 = S.make_state_dict(C.TINY, 0)
     for k in sd1:
         assert torch.equal(sd1[k], sd2[k])
+
+
+def test_nights_decision_rule():
+    from diffsim_amd import harness as Hn
+    sl = torch.tensor([0.9, 0.2, 0.5]); sr = torch.tensor([0.1, 0.8, 0.5])
+    assert Hn.nights_decisions(sl, sr, "cosine").tolist() == [1, 0, 0]      # night_main.py:160-161
+    assert Hn.nights_decisions(sl, sr, "mse").tolist() == [0, 1, 0]         # night_main.py:158-159
+    assert abs(Hn.nights_accuracy(sl, sr, [1, 0, 1], "cosine") - 200.0 / 3) < 1e-4
+    assert Hn.cute_accuracy(sl, sr) == pytest.approx(100.0 / 3)

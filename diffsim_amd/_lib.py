@@ -34,6 +34,9 @@ class UNetCfgC(C.Structure):
         ("cross_attention_dim", C.c_int32), ("norm_num_groups", C.c_int32),
         ("norm_eps", C.c_float), ("sample_size", C.c_int32), ("ctx_len", C.c_int32),
         ("compute_dtype", C.c_int32), ("tap_block", C.c_int32), ("tap_layer", C.c_int32),
+        ("tap_attn", C.c_int32), ("tap_tfm", C.c_int32),
+        ("heads_per_level", C.c_int32 * MAX_LEVELS), ("depth_per_level", C.c_int32 * MAX_LEVELS),
+        ("addition_embed", C.c_int32), ("addition_time_embed_dim", C.c_int32), ("pooled_dim", C.c_int32),
     ]
 
 
@@ -56,6 +59,7 @@ SYMBOLS = {
     "dsim_unet_load_weight": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(C.c_int64), _i]),
     "dsim_unet_finalize": (_i, [_vp, _vp]),
     "dsim_unet_set_timestep": (_i, [_vp, _i, _vp]),
+    "dsim_unet_set_conditioning": (_i, [_vp, _i, _vp, _vp, _vp]),
     "dsim_unet_workspace_bytes": (_sz, [_vp, _i]),
     "dsim_unet_qkv": (_i, [_vp, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dsim_unet_tap_shape": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
@@ -94,7 +98,7 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.dsim_version() != 1:
+        if L.dsim_version() != 2:
             raise DsimError("ABI version mismatch")
         _lib = L
     return _lib

@@ -8,7 +8,7 @@ state-dict keys, so a real ``diffusion_pytorch_model.safetensors`` can be fed un
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 
 @dataclass(frozen=True)
@@ -28,10 +28,24 @@ class UNetConfig:
     sample_size: int = 64                  # latent side (image side / 8)
     transformer_layers_per_block: int = 1
     ctx_len: int = 77
+    # ---- SDXL deltas; None/False = SD1.5 behaviour -----------------
+    heads_per_level: Optional[Tuple[int, ...]] = None       # (5, 10, 20): head_dim 64
+    depth_per_level: Optional[Tuple[int, ...]] = None       # transformer_layers_per_block (1, 2, 10)
+    use_linear_projection: bool = False
+    addition_embed: bool = False                             # addition_embed_type "text_time"
+    addition_time_embed_dim: int = 256
+    pooled_dim: int = 1280
+    sdxl_tap: bool = False                                   # [block, attention, transformer_block] addressing
 
     @property
     def time_embed_dim(self) -> int:
         return self.block_out_channels[0] * 4
+
+    def heads(self, level: int) -> int:
+        return self.heads_per_level[level] if self.heads_per_level else self.num_attention_heads
+
+    def depth(self, level: int) -> int:
+        return self.depth_per_level[level] if self.depth_per_level else self.transformer_layers_per_block
 
 
 SD15 = UNetConfig()
@@ -41,6 +55,18 @@ SD15_SMALL = UNetConfig(sample_size=8)
 #: small-channel stand-in with identical topology (fast CPU tests)
 TINY = UNetConfig(block_out_channels=(64, 128, 256, 256), num_attention_heads=4,
                   cross_attention_dim=128, sample_size=16, ctx_len=13)
+#: SDXL base U-Net (BASELINE.json config 4): 3 levels, no attention at level 0, transformer depth 1/2/10
+SDXL = UNetConfig(block_out_channels=(320, 640, 1280),
+                  down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                  up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+                  cross_attention_dim=2048, sample_size=128, heads_per_level=(5, 10, 20), depth_per_level=(1, 2, 10),
+                  use_linear_projection=True, addition_embed=True, sdxl_tap=True)
+SDXL_TINY = UNetConfig(block_out_channels=(64, 128, 256),
+                       down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                       up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+                       cross_attention_dim=128, sample_size=16, ctx_len=13, heads_per_level=(1, 2, 4),
+                       depth_per_level=(1, 2, 3), use_linear_projection=True, addition_embed=True,
+                       addition_time_embed_dim=32, pooled_dim=64, sdxl_tap=True)
 
 
 def _resnet(p: str, cin: int, cout: int, temb: int, out: Dict[str, Tuple[int, ...]]):
@@ -59,12 +85,13 @@ def _resnet(p: str, cin: int, cout: int, temb: int, out: Dict[str, Tuple[int, ..
         out[p + "conv_shortcut.bias"] = (cout,)
 
 
-def _transformer(p: str, c: int, cfg: UNetConfig, out: Dict[str, Tuple[int, ...]]):
+def _transformer(p: str, c: int, cfg: UNetConfig, out: Dict[str, Tuple[int, ...]], level: int = 0):
+    proj = (c, c) if cfg.use_linear_projection else (c, c, 1, 1)
     out[p + "norm.weight"] = (c,)
     out[p + "norm.bias"] = (c,)
-    out[p + "proj_in.weight"] = (c, c, 1, 1)
+    out[p + "proj_in.weight"] = proj
     out[p + "proj_in.bias"] = (c,)
-    for j in range(cfg.transformer_layers_per_block):
+    for j in range(cfg.depth(level)):
         q = f"{p}transformer_blocks.{j}."
         for n in ("norm1", "norm2", "norm3"):
             out[q + n + ".weight"] = (c,)
@@ -83,7 +110,7 @@ def _transformer(p: str, c: int, cfg: UNetConfig, out: Dict[str, Tuple[int, ...]
         out[q + "ff.net.0.proj.bias"] = (8 * c,)
         out[q + "ff.net.2.weight"] = (c, 4 * c)
         out[q + "ff.net.2.bias"] = (c,)
-    out[p + "proj_out.weight"] = (c, c, 1, 1)
+    out[p + "proj_out.weight"] = proj
     out[p + "proj_out.bias"] = (c,)
 
 
@@ -98,19 +125,25 @@ def unet_param_shapes(cfg: UNetConfig) -> Dict[str, Tuple[int, ...]]:
     out["time_embedding.linear_1.bias"] = (temb,)
     out["time_embedding.linear_2.weight"] = (temb, temb)
     out["time_embedding.linear_2.bias"] = (temb,)
+    if cfg.addition_embed:
+        ain = cfg.pooled_dim + 6 * cfg.addition_time_embed_dim
+        out["add_embedding.linear_1.weight"] = (temb, ain)
+        out["add_embedding.linear_1.bias"] = (temb,)
+        out["add_embedding.linear_2.weight"] = (temb, temb)
+        out["add_embedding.linear_2.bias"] = (temb,)
     prev = ch[0]
     for i, typ in enumerate(cfg.down_block_types):
         cin, prev = prev, ch[i]
         for j in range(cfg.layers_per_block):
             _resnet(f"down_blocks.{i}.resnets.{j}.", cin if j == 0 else ch[i], ch[i], temb, out)
             if typ == "CrossAttnDownBlock2D":
-                _transformer(f"down_blocks.{i}.attentions.{j}.", ch[i], cfg, out)
+                _transformer(f"down_blocks.{i}.attentions.{j}.", ch[i], cfg, out, i)
         if i != len(ch) - 1:
             out[f"down_blocks.{i}.downsamplers.0.conv.weight"] = (ch[i], ch[i], 3, 3)
             out[f"down_blocks.{i}.downsamplers.0.conv.bias"] = (ch[i],)
     c = ch[-1]
     _resnet("mid_block.resnets.0.", c, c, temb, out)
-    _transformer("mid_block.attentions.0.", c, cfg, out)
+    _transformer("mid_block.attentions.0.", c, cfg, out, len(ch) - 1)
     _resnet("mid_block.resnets.1.", c, c, temb, out)
     rev = list(reversed(ch))
     o = rev[0]
@@ -123,7 +156,7 @@ def unet_param_shapes(cfg: UNetConfig) -> Dict[str, Tuple[int, ...]]:
             rin = prv if j == 0 else o
             _resnet(f"up_blocks.{i}.resnets.{j}.", rin + skip, o, temb, out)
             if typ == "CrossAttnUpBlock2D":
-                _transformer(f"up_blocks.{i}.attentions.{j}.", o, cfg, out)
+                _transformer(f"up_blocks.{i}.attentions.{j}.", o, cfg, out, len(ch) - 1 - i)
         if i != len(ch) - 1:
             out[f"up_blocks.{i}.upsamplers.0.conv.weight"] = (o, o, 3, 3)
             out[f"up_blocks.{i}.upsamplers.0.conv.bias"] = (o,)

@@ -47,6 +47,8 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0;                    // N counts packed weight rows (2x out cols for GEGLU)
     const void* W = nullptr;                    // packed [N][K], compute dtype
     const float* bias = nullptr;                // [N] f32 (packed order) or null
+    const float* bias2 = nullptr;               // optional: bias of ODD batch elements (m / rows_per_batch) & 1 -- SDXL's
+    int rows_per_batch = 0;                     //   time embedding differs between the uncond/cond CFG halves
     int epi = EPI_NONE;
     const void* residual = nullptr;             // [M][ldo]
     void* out = nullptr;
@@ -71,6 +73,7 @@ int gemv_f32(const void* W, int w_dtype, const void* bias, int b_dtype, const fl
              int N, int K, int act, hipStream_t s);
 int add_vectors_f32(const float* a, const float* b, float* out, int N, hipStream_t s);
 int timestep_sincos(float* out, int dim, int t, hipStream_t s);
+int sincos_values(float* out, int dim, const float* vals /*device*/, int count, hipStream_t s);
 
 // noising + CFG duplication + conv_in (direct) -- pack.hip
 //   x_t = sa*lat + sb*noise ; out[(img*2+cfg)][pix][co] for cfg in {0,1}

@@ -373,9 +373,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                     for (int e = 0; e < 4; ++e) v[e] = t4[e];
                 }
                 if (!GEGLU && p.bias) {
+                    const float* bsel = (p.bias2 && ((m / p.rows_per_batch) & 1)) ? p.bias2 : p.bias;
 #pragma unroll
                     for (int e = 0; e < VEC; e += 4) {
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + nout0 + ncol + e);
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bsel + nout0 + ncol + e);
 #pragma unroll
                         for (int f = 0; f < 4; ++f) v[e + f] += b4[f];
                     }

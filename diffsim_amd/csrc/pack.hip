@@ -90,6 +90,18 @@ __global__ void timestep_kernel(float* out, int dim, int t) {
     out[half + i] = sinf(e);
 }
 
+// the same embedding for `count` float values read from device memory: out[v][dim] (SDXL time_ids)
+__global__ void sincos_values_kernel(float* out, int dim, const float* vals, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (i >= half * count) return;
+    const int v = i / half, j = i - v * half;
+    const float f = expf(-logf(10000.0f) * (float)j / (float)half);
+    const float e = vals[v] * f;
+    out[(size_t)v * dim + j] = cosf(e);
+    out[(size_t)v * dim + half + j] = sinf(e);
+}
+
 // x_t = sa*lat + sb*noise (NCHW f32), 3x3 conv (pad 1) to Cout, written twice (CFG halves are
 // identical at this point) as token-major [img*2 + cfg][pix][Cout].
 // block = 256 threads handles PIX pixels of one image; w is [tap*Cin + ci][Cout] f32.
@@ -181,6 +193,11 @@ int add_vectors_f32(const float* a, const float* b, float* out, int N, hipStream
 }
 int timestep_sincos(float* out, int dim, int t, hipStream_t s) {
     hipLaunchKernelGGL(timestep_kernel, dim3((dim / 2 + 255) / 256), dim3(256), 0, s, out, dim, t);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+int sincos_values(float* out, int dim, const float* vals, int count, hipStream_t s) {
+    hipLaunchKernelGGL(sincos_values_kernel, dim3((dim / 2 * count + 255) / 256), dim3(256), 0, s, out, dim, vals, count);
     DSIM_HIP_CHECK(hipGetLastError());
     return DSIM_OK;
 }

@@ -143,7 +143,8 @@ static inline int pack_all(WeightStore* h, hipStream_t s) {
                 Packed& F = h->pk[fk];
                 if (!F.p) { CK(h->dalloc((size_t)2 * n * k * es, &F.p)); F.rows = 2 * n; F.cols = k; }
                 CK(pack_linear(w.p, w.dtype, (char*)F.p + (size_t)(is_k2 ? 0 : 1) * n * k * es, dt, n, k, 0, s));
-            } else if (ends_with(key, "time_emb_proj.weight") || key.rfind("time_embedding.", 0) == 0) {
+            } else if (ends_with(key, "time_emb_proj.weight") || key.rfind("time_embedding.", 0) == 0 ||
+                       key.rfind("add_embedding.", 0) == 0) {
                 CK(h->dalloc((size_t)n * k * 4, &P.p));        // kept f32: consumed by the GEMV
                 P.rows = n; P.cols = k;
                 CK(pack_linear(w.p, w.dtype, P.p, DSIM_F32, n, k, 0, s));

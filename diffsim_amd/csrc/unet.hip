@@ -29,6 +29,7 @@ struct dsim_unet : WeightStore {
     int timestep = -1;
     float* temb = nullptr;          // [time_embed_dim]
     float* tscratch = nullptr;      // time-embedding scratch
+    bool two_temb = false;          // SDXL: the CFG halves carry different time embeddings
 };
 
 namespace {
@@ -98,8 +99,9 @@ struct Walk {
         return gemm(g);
     }
     int conv3(const Act& x, const Packed* w, const float* bias, const void* residual, void* out, int Cout, int stride,
-              int ups) {
+              int ups, const float* bias_odd = nullptr) {
         GemmArgs g;
+        if (h->two_temb && bias_odd) { g.bias2 = bias_odd; g.rows_per_batch = (ups ? 4 : 1) * x.H * x.W / (stride == 2 ? 4 : 1); }
         g.A0 = x.p; g.C0 = x.C; g.mode = GEMM_CONV3;
         g.Hin = x.H; g.Win = x.W;
         g.Hout = ups ? x.H * 2 : (stride == 2 ? x.H / 2 : x.H);
@@ -142,7 +144,7 @@ struct Walk {
     int resnet(const std::string& p, const Act& x0, const Act* x1, int Cout, Act* out) {
         const int Cin = x0.C + (x1 ? x1->C : 0), HW = x0.H * x0.W, M = B2 * HW;
         WGET(n1w, p + "norm1.weight"); WGET(n1b, p + "norm1.bias");
-        WGET(c1w, p + "conv1.weight"); WGET(c1b, p + "conv1.bias_eff");
+        WGET(c1w, p + "conv1.weight"); WGET(c1b, p + "conv1.bias_eff"); WGET(c1b2, p + "conv1.bias_eff2");
         WGET(n2w, p + "norm2.weight"); WGET(n2b, p + "norm2.bias");
         WGET(c2w, p + "conv2.weight"); WGET(c2b, p + "conv2.bias");
         out->p = alloc_act((size_t)M * Cout); out->C = Cout; out->H = x0.H; out->W = x0.W;
@@ -150,7 +152,7 @@ struct Walk {
         Act t1{alloc_act((size_t)M * Cin), Cin, x0.H, x0.W};
         CK(gn(x0, x1, n1w, n1b, t1.p, h->cfg.norm_eps, 1));
         Act t2{alloc_act((size_t)M * Cout), Cout, x0.H, x0.W};
-        CK(conv3(t1, c1w, (const float*)c1b->p, nullptr, t2.p, Cout, 1, 0));
+        CK(conv3(t1, c1w, (const float*)c1b->p, nullptr, t2.p, Cout, 1, 0, (const float*)c1b2->p));
         Act t3{alloc_act((size_t)M * Cout), Cout, x0.H, x0.W};
         CK(gn(t2, nullptr, n2w, n2b, t3.p, h->cfg.norm_eps, 1));
         const void* res = x0.p;
@@ -167,24 +169,37 @@ struct Walk {
         return DSIM_OK;
     }
 
-    // Transformer2DModel with one BasicTransformerBlock; `tap` stops after norm1 and emits q,k,v
-    int transformer(const std::string& p, const Act& x, bool tap, Act* out) {
-        const int C = x.C, HW = x.H * x.W, M = B2 * HW, H = h->cfg.num_heads, D = C / H;
+    int heads_at(int level) const { return h->cfg.heads_per_level[level] > 0 ? h->cfg.heads_per_level[level] : h->cfg.num_heads; }
+    int depth_at(int level) const { return h->cfg.depth_per_level[level] > 0 ? h->cfg.depth_per_level[level] : 1; }
+
+    // Transformer2DModel (GroupNorm -> proj_in -> `depth` BasicTransformerBlocks -> proj_out -> +residual; the
+    // conv1x1 and the Linear form of proj_in/out are the same GEMM on token-major data).  tap_blk >= 0 stops
+    // after norm1 of that transformer block and emits q,k,v (-2 = never, -1 = the last block).
+    int transformer(const std::string& p, const Act& x, int level, int tap_blk, Act* out) {
+        const int C = x.C, HW = x.H * x.W, M = B2 * HW, H = heads_at(level), D = C / H;
         const int L = h->cfg.ctx_len, Dc = h->cfg.cross_attention_dim;
-        const std::string b = p + "transformer_blocks.0.";
+        const int depth = depth_at(level);
+        if (tap_blk == -1) tap_blk = depth - 1;
+        if (tap_blk >= depth) return DSIM_ERR_INVALID;
+        const bool tap_here = tap_blk >= 0;
         WGET(gnw, p + "norm.weight"); WGET(gnb, p + "norm.bias");
         WGET(piw, p + "proj_in.weight"); WGET(pib, p + "proj_in.bias");
-        WGET(l1w, b + "norm1.weight"); WGET(l1b, b + "norm1.bias");
-        WGET(qkv, b + "attn1.qkv");
-        if (!tap) { out->p = alloc_act((size_t)M * C); out->C = C; out->H = x.H; out->W = x.W; }
+        if (!tap_here) { out->p = alloc_act((size_t)M * C); out->C = C; out->H = x.H; out->W = x.W; }
         const size_t mk = ar->mark();
         void* t1 = alloc_act((size_t)M * C);
         CK(gn(x, nullptr, gnw, gnb, t1, 1e-6f, 0));
         void* hb = alloc_act((size_t)M * C);
         CK(linear(t1, C, nullptr, 0, piw, pib, nullptr, hb, M, C, C));
         void* nb = t1;                                   // t1 is dead: reuse it for LayerNorm outputs
+        void* big = nullptr;
+        void* ab = nullptr;
+        void* kvb = nullptr;
+        for (int blk = 0; blk < depth; ++blk) {
+        const std::string b = p + "transformer_blocks." + std::to_string(blk) + ".";
+        WGET(l1w, b + "norm1.weight"); WGET(l1b, b + "norm1.bias");
+        WGET(qkv, b + "attn1.qkv");
         CK(ln(hb, l1w, l1b, nb, M, C));
-        if (tap) {
+        if (blk == tap_blk) {
             // hacked_attn.py:61-69: to_q / to_k / to_v, no bias; written [B][N][H*D]
             Packed wq = *qkv, wk = *qkv, wv = *qkv;
             wk.p = (char*)qkv->p + (size_t)C * C * es();
@@ -203,10 +218,12 @@ struct Walk {
         WGET(l3w, b + "norm3.weight"); WGET(l3b, b + "norm3.bias");
         WGET(f1w, b + "ff.net.0.proj.weight"); WGET(f1b, b + "ff.net.0.proj.bias");
         WGET(f2w, b + "ff.net.2.weight"); WGET(f2b, b + "ff.net.2.bias");
-        WGET(pow_, p + "proj_out.weight"); WGET(pob, p + "proj_out.bias");
         // self-attention
-        void* big = alloc_act((size_t)M * 4 * C);        // qkv [M][3C], later GEGLU out [M][4C]
-        void* ab = alloc_act((size_t)M * C);
+        if (!big) {
+            big = alloc_act((size_t)M * 4 * C);          // qkv [M][3C], later GEGLU out [M][4C]
+            ab = alloc_act((size_t)M * C);
+            kvb = alloc_act((size_t)2 * L * 2 * C);
+        }
         CK(linear(nb, C, nullptr, 0, qkv, nullptr, nullptr, big, M, 3 * C, 3 * C));
         {
             AttnArgs a;
@@ -219,7 +236,6 @@ struct Walk {
         // cross-attention against the prompt context: batch element b uses ctx[b % 2]
         CK(ln(hb, l2w, l2b, nb, M, C));
         CK(linear(nb, C, nullptr, 0, q2w, nullptr, nullptr, ab, M, C, C));
-        void* kvb = alloc_act((size_t)2 * L * 2 * C);
         CK(linear(ctx_t, Dc, nullptr, 0, kv2, nullptr, nullptr, kvb, 2 * L, 2 * C, 2 * C));
         {
             AttnArgs a;
@@ -233,6 +249,8 @@ struct Walk {
         CK(ln(hb, l3w, l3b, nb, M, C));
         CK(linear(nb, C, nullptr, 0, f1w, f1b, nullptr, big, M, 8 * C, 4 * C, EPI_GEGLU));
         CK(linear(big, 4 * C, nullptr, 0, f2w, f2b, hb, hb, M, C, C));
+        }   // transformer blocks
+        WGET(pow_, p + "proj_out.weight"); WGET(pob, p + "proj_out.bias");
         CK(linear(hb, C, nullptr, 0, pow_, pob, x.p, out->p, M, C, C));
         ar->release(mk);
         return DSIM_OK;
@@ -265,9 +283,10 @@ struct Walk {
                 CK(resnet(bp + "resnets." + std::to_string(j) + ".", x, nullptr, co, &r));
                 x = r;
                 if (c.down_has_attn[i]) {
-                    const bool tap = c.tap_block == DSIM_TAP_DOWN && c.tap_layer == i && j == c.layers_per_block - 1;
+                    const int ta = c.tap_attn < 0 ? c.layers_per_block - 1 : c.tap_attn;
+                    const bool tap = c.tap_block == DSIM_TAP_DOWN && c.tap_layer == i && j == ta;
                     Act t;
-                    CK(transformer(bp + "attentions." + std::to_string(j) + ".", x, tap, &t));
+                    CK(transformer(bp + "attentions." + std::to_string(j) + ".", x, i, tap ? c.tap_tfm : -2, &t));
                     if (tap) return DSIM_OK;
                     x = t;
                 }
@@ -289,7 +308,7 @@ struct Walk {
             x = r;
             const bool tap = c.tap_block == DSIM_TAP_MID;
             Act t;
-            CK(transformer("mid_block.attentions.0.", x, tap, &t));
+            CK(transformer("mid_block.attentions.0.", x, nl - 1, tap ? c.tap_tfm : -2, &t));
             if (tap) return DSIM_OK;
             x = t;
             CK(resnet("mid_block.resnets.1.", x, nullptr, cm, &r));
@@ -308,9 +327,10 @@ struct Walk {
                 CK(resnet(bp + "resnets." + std::to_string(j) + ".", x, &sk, co, &r));
                 x = r;
                 if (c.up_has_attn[i]) {
-                    const bool tap = c.tap_block == DSIM_TAP_UP && c.tap_layer + 1 == i && j == nres - 1;
+                    const int ta = c.tap_attn < 0 ? nres - 1 : c.tap_attn;
+                    const bool tap = c.tap_block == DSIM_TAP_UP && c.tap_layer == i && j == ta;
                     Act t;
-                    CK(transformer(bp + "attentions." + std::to_string(j) + ".", x, tap, &t));
+                    CK(transformer(bp + "attentions." + std::to_string(j) + ".", x, nl - 1 - i, tap ? c.tap_tfm : -2, &t));
                     if (tap) return DSIM_OK;
                     x = t;
                 }
@@ -330,22 +350,29 @@ int tap_geometry(const dsim_unet_cfg& c, int* tokens, int* heads, int* hd) {
     const int nl = c.n_levels;
     int level;   // resolution level of the tapped block
     if (c.tap_block == DSIM_TAP_DOWN) {
-        if (c.tap_layer < 0 || c.tap_layer >= nl - 1 || !c.down_has_attn[c.tap_layer]) return DSIM_ERR_INVALID;
+        if (c.tap_layer < 0 || c.tap_layer >= nl || !c.down_has_attn[c.tap_layer]) return DSIM_ERR_INVALID;
+        if (c.tap_attn >= c.layers_per_block) return DSIM_ERR_INVALID;
         level = c.tap_layer;
     } else if (c.tap_block == DSIM_TAP_MID) {
+        if (c.tap_attn > 0) return DSIM_ERR_INVALID;
         level = nl - 1;
     } else if (c.tap_block == DSIM_TAP_UP) {
-        const int i = c.tap_layer + 1;
-        if (c.tap_layer < 0 || i >= nl || !c.up_has_attn[i]) return DSIM_ERR_INVALID;
+        const int i = c.tap_layer;
+        if (i < 0 || i >= nl || !c.up_has_attn[i]) return DSIM_ERR_INVALID;
+        if (c.tap_attn > c.layers_per_block) return DSIM_ERR_INVALID;
         level = nl - 1 - i;
     } else {
         return DSIM_ERR_INVALID;
     }
+    const int depth = c.depth_per_level[level] > 0 ? c.depth_per_level[level] : 1;
+    if (c.tap_tfm >= depth) return DSIM_ERR_INVALID;
+    // spatial side at that level: one downsample per level except after the last
     const int side = c.sample_size >> level;
     const int C = c.block_out_channels[level];
+    const int H = c.heads_per_level[level] > 0 ? c.heads_per_level[level] : c.num_heads;
     *tokens = side * side;
-    *heads = c.num_heads;
-    *hd = C / c.num_heads;
+    *heads = H;
+    *hd = C / H;
     return DSIM_OK;
 }
 
@@ -417,18 +444,22 @@ int dsim_unet_finalize(dsim_unet* h, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     CK(pack_all(h, s));
     const int ted = h->cfg.block_out_channels[0] * 4;
-    CK(h->dalloc((size_t)ted * 4, (void**)&h->temb));
-    CK(h->dalloc((size_t)(ted * 2 + h->cfg.block_out_channels[0]) * 4, (void**)&h->tscratch));
-    // conv1.bias_eff buffers (conv1.bias + time_emb_proj(silu(temb))) are filled by set_timestep
+    const int addin = h->cfg.addition_embed ? h->cfg.pooled_dim + 6 * h->cfg.addition_time_embed_dim : 0;
+    CK(h->dalloc((size_t)2 * ted * 4, (void**)&h->temb));
+    CK(h->dalloc((size_t)(h->cfg.block_out_channels[0] + 5 * ted + addin + 64) * 4, (void**)&h->tscratch));
+    // conv1.bias_eff / bias_eff2 (conv1.bias + time_emb_proj(silu(temb)) for the even / odd CFG half) are
+    // filled by set_timestep / set_conditioning
     std::vector<std::string> res;
     for (auto& kv : h->pk)
         if (ends_with(kv.first, "time_emb_proj.weight")) res.push_back(kv.first);
     for (auto& k : res) {
         const std::string p = k.substr(0, k.size() - strlen("time_emb_proj.weight"));
-        Packed P;
-        P.rows = h->pk[k].rows; P.cols = 1;
-        CK(h->dalloc((size_t)P.rows * 4, &P.p));
-        h->pk[p + "conv1.bias_eff"] = P;
+        for (const char* suffix : {"conv1.bias_eff", "conv1.bias_eff2"}) {
+            Packed P;
+            P.rows = h->pk[k].rows; P.cols = 1;
+            CK(h->dalloc((size_t)P.rows * 4, &P.p));
+            h->pk[p + suffix] = P;
+        }
     }
     DSIM_HIP_CHECK(hipStreamSynchronize(s));
     h->raw.clear();
@@ -441,14 +472,18 @@ int dsim_unet_finalize(dsim_unet* h, void* stream) {
     return DSIM_OK;
 }
 
-int dsim_unet_set_timestep(dsim_unet* h, int t, void* stream) {
-    if (!h || t < 0) return DSIM_ERR_INVALID;
-    if (!h->finalized) return DSIM_ERR_STATE;
-    hipStream_t s = (hipStream_t)stream;
-    const int ch0 = h->cfg.block_out_channels[0], ted = ch0 * 4;
+static int set_cond(dsim_unet* h, int t, const float* text_embeds, const float* time_ids, hipStream_t s) {
+    const dsim_unet_cfg& c = h->cfg;
+    const int ch0 = c.block_out_channels[0], ted = ch0 * 4;
+    const bool add = c.addition_embed != 0;
+    if (add && (!text_embeds || !time_ids)) return DSIM_ERR_INVALID;
     float* emb = h->tscratch;              // [ch0]
-    float* h1 = h->tscratch + ch0;         // [ted]
-    float* tp = h1 + ted;                  // [<= ted] per-resnet projection
+    float* h1 = emb + ch0;                 // [ted]
+    float* tp = h1 + ted;                  // [ted] per-resnet projection
+    float* base = tp + ted;                // [ted] time_embedding(t)
+    float* a1 = base + ted;                // [ted]
+    float* aug = a1 + ted;                 // [ted]
+    float* ain = aug + ted;                // [pooled + 6*atd]
     const Packed* w1 = h->find("time_embedding.linear_1.weight");
     const Packed* b1 = h->find("time_embedding.linear_1.bias");
     const Packed* w2 = h->find("time_embedding.linear_2.weight");
@@ -456,21 +491,54 @@ int dsim_unet_set_timestep(dsim_unet* h, int t, void* stream) {
     if (!w1 || !b1 || !w2 || !b2) return DSIM_ERR_MISSING_WEIGHT;
     CK(timestep_sincos(emb, ch0, t, s));
     CK(gemv_f32(w1->p, DSIM_F32, b1->p, DSIM_F32, emb, h1, ted, ch0, 0, s));
-    CK(gemv_f32(w2->p, DSIM_F32, b2->p, DSIM_F32, h1, h->temb, ted, ted, 1, s));
-    for (auto& kv : h->pk) {
-        if (!ends_with(kv.first, "time_emb_proj.weight")) continue;
-        const std::string p = kv.first.substr(0, kv.first.size() - strlen("time_emb_proj.weight"));
-        const Packed* tb = h->find(p + "time_emb_proj.bias");
-        const Packed* cb = h->find(p + "conv1.bias");
-        const Packed* eff = h->find(p + "conv1.bias_eff");
-        if (!tb || !cb || !eff) return DSIM_ERR_MISSING_WEIGHT;
-        const int n = kv.second.rows;
-        if (n > ted) return DSIM_ERR_INVALID;
-        CK(gemv_f32(kv.second.p, DSIM_F32, tb->p, DSIM_F32, h->temb, tp, n, ted, 1, s));
-        CK(add_vectors_f32((const float*)cb->p, tp, (float*)eff->p, n, s));
+    CK(gemv_f32(w2->p, DSIM_F32, b2->p, DSIM_F32, h1, base, ted, ted, 1, s));
+    for (int half = 0; half < 2; ++half) {
+        float* temb = h->temb + (size_t)half * ted;
+        if (add) {
+            // UNet2DConditionModel "text_time": cat(text_embeds, Timesteps(time_ids.flatten())) -> add_embedding
+            const Packed* aw1 = h->find("add_embedding.linear_1.weight");
+            const Packed* ab1 = h->find("add_embedding.linear_1.bias");
+            const Packed* aw2 = h->find("add_embedding.linear_2.weight");
+            const Packed* ab2 = h->find("add_embedding.linear_2.bias");
+            if (!aw1 || !ab1 || !aw2 || !ab2) return DSIM_ERR_MISSING_WEIGHT;
+            const int P = c.pooled_dim, atd = c.addition_time_embed_dim, nin = P + 6 * atd;
+            DSIM_HIP_CHECK(hipMemcpyAsync(ain, text_embeds + (size_t)half * P, (size_t)P * 4, hipMemcpyDeviceToDevice, s));
+            CK(sincos_values(ain + P, atd, time_ids + (size_t)half * 6, 6, s));
+            CK(gemv_f32(aw1->p, DSIM_F32, ab1->p, DSIM_F32, ain, a1, ted, nin, 0, s));
+            CK(gemv_f32(aw2->p, DSIM_F32, ab2->p, DSIM_F32, a1, aug, ted, ted, 1, s));
+            CK(add_vectors_f32(base, aug, temb, ted, s));
+        } else {
+            DSIM_HIP_CHECK(hipMemcpyAsync(temb, base, (size_t)ted * 4, hipMemcpyDeviceToDevice, s));
+        }
+        for (auto& kv : h->pk) {
+            if (!ends_with(kv.first, "time_emb_proj.weight")) continue;
+            const std::string p = kv.first.substr(0, kv.first.size() - strlen("time_emb_proj.weight"));
+            const Packed* tb = h->find(p + "time_emb_proj.bias");
+            const Packed* cb = h->find(p + "conv1.bias");
+            const Packed* eff = h->find(p + (half ? "conv1.bias_eff2" : "conv1.bias_eff"));
+            if (!tb || !cb || !eff) return DSIM_ERR_MISSING_WEIGHT;
+            const int n = kv.second.rows;
+            if (n > ted) return DSIM_ERR_INVALID;
+            CK(gemv_f32(kv.second.p, DSIM_F32, tb->p, DSIM_F32, temb, tp, n, ted, 1, s));
+            CK(add_vectors_f32((const float*)cb->p, tp, (float*)eff->p, n, s));
+        }
     }
+    h->two_temb = add;
     h->timestep = t;
     return DSIM_OK;
+}
+
+int dsim_unet_set_timestep(dsim_unet* h, int t, void* stream) {
+    if (!h || t < 0) return DSIM_ERR_INVALID;
+    if (!h->finalized) return DSIM_ERR_STATE;
+    if (h->cfg.addition_embed) return DSIM_ERR_STATE;       // SDXL graphs need set_conditioning
+    return set_cond(h, t, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int dsim_unet_set_conditioning(dsim_unet* h, int t, const float* text_embeds, const float* time_ids, void* stream) {
+    if (!h || t < 0) return DSIM_ERR_INVALID;
+    if (!h->finalized) return DSIM_ERR_STATE;
+    return set_cond(h, t, text_embeds, time_ids, (hipStream_t)stream);
 }
 
 size_t dsim_unet_workspace_bytes(const dsim_unet* hc, int n_images) {

@@ -1,0 +1,94 @@
+"""DiffSim-XL scorer (SDXL U-Net) with the reference's entry points, backed by the MI355X engine.
+
+Mirrors ``/root/reference/diffsim/diffsim_xl.py`` (``diffsim_xl.__init__`` :48-56, ``prepare_image_latents``
+:58-63, ``diffsim_score`` :65-155) and what ``DiffSimXLPipeline.step`` does around the U-Net call
+(``/root/reference/diffsim/diffsim_xl_pipeline.py:163-323``): prompt + pooled embeddings, Euler
+index -> (t, sigma), latents * init_noise_sigma + sigma*noise, / sqrt(sigma^2+1), CFG duplication,
+``added_cond_kwargs = {text_embeds, time_ids}``.  ``target_layer`` is the reference's 3-int address
+``[block, attention, transformer_block]`` (2 ints for mid_blocks).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+from . import scheduler as sched
+from .config import SDXL, UNetConfig
+from .diffsim import get_generator
+from .engine import UNetEngine, pair_score
+from .image import load_image, process_image
+
+
+class diffsim_xl:
+    def __init__(self, torch_dtype=torch.bfloat16, device="cuda", ip_adapter=False, *, unet_config: UNetConfig = SDXL,
+                 state_dict: Optional[Dict[str, torch.Tensor]] = None, vae=None,
+                 encode_prompt: Optional[Callable[[str], Tuple[torch.Tensor, torch.Tensor]]] = None):
+        if ip_adapter:
+            raise NotImplementedError("IP-Adapter mode is out of scope")
+        if state_dict is None:
+            raise ValueError("state_dict (diffusers-keyed SDXL U-Net weights) is required")
+        if torch_dtype == torch.float16:
+            torch_dtype = torch.bfloat16
+        self.dtype = torch_dtype
+        self.device = torch.device("cuda:0" if device == "cuda" else device)
+        self.ip_adapter = False
+        self.cfg, self.state_dict, self.vae, self._encode_prompt = unet_config, state_dict, vae, encode_prompt
+        self._engines: Dict[tuple, UNetEngine] = {}
+
+    def engine(self, target_block: str, target_layer) -> UNetEngine:
+        key = (target_block, tuple(int(v) for v in target_layer))
+        if key not in self._engines:
+            self._engines[key] = UNetEngine(self.cfg, self.state_dict, self.dtype, target_block, list(key[1]), str(self.device))
+        return self._engines[key]
+
+    def prepare_image_latents(self, image, generator=None):
+        if self.vae is None:
+            raise RuntimeError("no VAE plugged in: use score_latent_pairs")
+        lat = self.vae.encode(image.to(dtype=torch.float32)).latent_dist.sample(generator=generator)
+        lat = self.vae.config.scaling_factor * lat
+        return lat.to(dtype=torch.float16)                         # diffsim_xl.py:63
+
+    def time_ids(self) -> torch.Tensor:
+        side = float(self.cfg.sample_size * 8)                     # height/width default to sample_size * 8
+        return torch.tensor([[side, side, 0.0, 0.0, side, side]] * 2, dtype=torch.float32)
+
+    @torch.no_grad()
+    def features(self, latents, noise, ctx, pooled, target_block, target_layer, target_step):
+        eng = self.engine(target_block, target_layer)
+        t, a, b = sched.sdxl_step_coefficients(int(target_step))
+        eng.set_conditioning(t, pooled, self.time_ids())
+        return eng.qkv(latents.to(self.device, torch.float32).contiguous(), noise.to(self.device, torch.float32).contiguous(),
+                       a, b, ctx.to(self.device, torch.float32).contiguous())
+
+    @torch.no_grad()
+    def score_latent_pairs(self, latA, latB, noiseA, noiseB, ctx, pooled, target_block, target_layer, target_step,
+                           similarity="cosine", batch_pairs: int = 8) -> torch.Tensor:
+        n = latA.shape[0]
+        eng = self.engine(target_block, target_layer)
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        shp = latA.shape[1:]
+        for i0 in range(0, n, batch_pairs):
+            i1 = min(n, i0 + batch_pairs)
+            m = i1 - i0
+            lat = torch.stack([latA[i0:i1], latB[i0:i1]], dim=1).reshape(2 * m, *shp).float()
+            nz = torch.stack([noiseA.expand(m, *shp), noiseB.expand(m, *shp)], dim=1).reshape(2 * m, *shp)
+            q, k, v = self.features(lat, nz, ctx, pooled, target_block, target_layer, target_step)
+            ia = torch.arange(0, 2 * m, 2, dtype=torch.int32, device=self.device)
+            out[i0:i1] = pair_score(q, k, v, ia, ia + 1, eng.heads, similarity)
+        return out
+
+    @torch.no_grad()
+    def diffsim_score(self, image_A, image_B, img_size, prompt, target_block, target_layer, target_step, similarity, seed):
+        """Same contract as the reference's ``diffsim_xl.diffsim_score`` (diffsim/diffsim_xl.py:65-155)."""
+        if self._encode_prompt is None:
+            raise RuntimeError("no text encoder plugged in: pass encode_prompt=...")
+        tensor_A, tensor_B = process_image(load_image(image_A), img_size), process_image(load_image(image_B), img_size)
+        generator = get_generator(seed, "cpu")
+        latentsA = self.prepare_image_latents(tensor_A, generator)
+        latentsB = self.prepare_image_latents(tensor_B, generator)
+        noiseA = torch.randn(latentsA.shape, generator=generator, dtype=torch.float32)
+        noiseB = torch.randn(latentsB.shape, generator=generator, dtype=torch.float32)
+        ctx, pooled = self._encode_prompt(prompt)
+        return self.score_latent_pairs(latentsA.float(), latentsB.float(), noiseA, noiseB, ctx, pooled, target_block,
+                                       target_layer, target_step, similarity)

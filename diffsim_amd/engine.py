@@ -32,7 +32,27 @@ def _require_cuda(*ts):
             raise _lib.DsimError("tensor must be contiguous")
 
 
-def _cfg_struct(cfg: UNetConfig, dtype: torch.dtype, tap_block: str, tap_layer: int) -> _lib.UNetCfgC:
+def resolve_tap(cfg: UNetConfig, target_block: str, target_layer):
+    """(absolute block index, attention index, transformer-block index) of the hooked attn1.
+    SD1.5 (diffsim/diffsim.py:122-145): down_blocks[:-1][l] / mid / up_blocks[1:][l], always attentions[-1]
+    .transformer_blocks[-1].  SDXL (diffsim/diffsim_xl.py:88-107): target_layer = [block, attention, tfm_block]
+    into down_blocks[1:] / up_blocks[:-1]; mid = [attention, tfm_block]."""
+    if not cfg.sdxl_tap:
+        l = int(target_layer)
+        if target_block == "down_blocks":
+            return l, -1, -1
+        if target_block == "mid_blocks":
+            return 0, -1, -1
+        return l + 1, -1, -1
+    tl = [int(v) for v in target_layer]
+    if target_block == "down_blocks":
+        return tl[0] + 1, tl[1], tl[2]
+    if target_block == "mid_blocks":
+        return 0, tl[0], tl[1]
+    return tl[0], tl[1], tl[2]
+
+
+def _cfg_struct(cfg: UNetConfig, dtype: torch.dtype, tap_block: str, tap_layer) -> _lib.UNetCfgC:
     c = _lib.UNetCfgC()
     n = len(cfg.block_out_channels)
     c.in_channels, c.n_levels = cfg.in_channels, n
@@ -40,6 +60,8 @@ def _cfg_struct(cfg: UNetConfig, dtype: torch.dtype, tap_block: str, tap_layer: 
         c.block_out_channels[i] = cfg.block_out_channels[i]
         c.down_has_attn[i] = int(cfg.down_block_types[i] == "CrossAttnDownBlock2D")
         c.up_has_attn[i] = int(cfg.up_block_types[i] == "CrossAttnUpBlock2D")
+        c.heads_per_level[i] = cfg.heads(i) if cfg.heads_per_level else 0
+        c.depth_per_level[i] = cfg.depth(i)
     c.layers_per_block = cfg.layers_per_block
     c.num_heads = cfg.num_attention_heads
     c.cross_attention_dim = cfg.cross_attention_dim
@@ -49,7 +71,10 @@ def _cfg_struct(cfg: UNetConfig, dtype: torch.dtype, tap_block: str, tap_layer: 
     c.ctx_len = cfg.ctx_len
     c.compute_dtype = _TORCH2DSIM[dtype]
     c.tap_block = _lib.TAP[tap_block]
-    c.tap_layer = int(tap_layer)
+    c.tap_layer, c.tap_attn, c.tap_tfm = resolve_tap(cfg, tap_block, tap_layer)
+    c.addition_embed = int(cfg.addition_embed)
+    c.addition_time_embed_dim = cfg.addition_time_embed_dim
+    c.pooled_dim = cfg.pooled_dim
     return c
 
 
@@ -68,7 +93,7 @@ class UNetEngine:
         if not torch.cuda.is_available():
             raise _lib.DsimError("no GPU visible: the DiffSim engine runs only on the HIP device")
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
-        self.target_block, self.target_layer = target_block, int(target_layer)
+        self.target_block, self.target_layer = target_block, target_layer
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             cs = _cfg_struct(cfg, dtype, target_block, target_layer)
@@ -108,6 +133,16 @@ class UNetEngine:
             with torch.cuda.device(self.device):
                 _lib.check(self.L.dsim_unet_set_timestep(self._h, int(t), _stream_ptr()), "set_timestep")
             self._t = t
+
+    def set_conditioning(self, t: int, text_embeds: torch.Tensor, time_ids: torch.Tensor):
+        """SDXL: timestep + added conditioning (pooled text embeds (2,P) [neg,pos], time ids (2,6))."""
+        te = text_embeds.to(self.device, torch.float32).contiguous()
+        ti = time_ids.to(self.device, torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.dsim_unet_set_conditioning(self._h, int(t), te.data_ptr(), ti.data_ptr(), _stream_ptr()),
+                       "set_conditioning")
+            torch.cuda.synchronize(self.device)     # te/ti may be freed by the caller
+        self._t = ("cond", t)
 
     def profile(self, enable: bool):
         _lib.check(self.L.dsim_unet_profile(self._h, int(enable)), "profile")

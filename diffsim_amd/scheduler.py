@@ -40,3 +40,27 @@ def timestep_from_index(target_step: int, num_inference_steps: int = 1000) -> in
 def noise_coefficients(t: int):
     ac = alphas_cumprod()
     return float(ac[t] ** 0.5), float((1.0 - ac[t]) ** 0.5)
+
+
+# ---- SDXL: EulerDiscreteScheduler with SDXL's scheduler_config ("leading" spacing, steps_offset 1) --------
+# reference call sites: diffsim/diffsim_xl_pipeline.py:190-225 (timesteps[i], prepare_latents * init_noise_sigma,
+# add_noise) and :309 (scale_model_input); semantics restated from SURVEY.md Appendix A item 14.
+def euler_tables(num_inference_steps: int = 1000, num_train_timesteps: int = 1000, steps_offset: int = 1):
+    ac = alphas_cumprod().numpy().astype(np.float64)
+    sig_all = ((1 - ac) / ac) ** 0.5
+    ratio = num_train_timesteps // num_inference_steps
+    ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.float32) + steps_offset
+    sig = np.interp(ts, np.arange(0, len(sig_all)), sig_all)
+    sig = np.concatenate([sig, [0.0]]).astype(np.float32)
+    return ts, sig, float((sig.max() ** 2 + 1) ** 0.5)
+
+
+def sdxl_step_coefficients(target_step: int):
+    """(t, a, b) with x_in = a*z0 + b*eps: the reference multiplies the CLEAN latents by init_noise_sigma,
+    adds sigma*eps, then divides by sqrt(sigma^2+1) (quirk reproduced)."""
+    ts, sig, init = euler_tables()
+    if not 0 <= target_step < len(ts):
+        raise IndexError(f"target_step {target_step} outside the {len(ts)}-entry timestep table")
+    s = float(sig[target_step])
+    d = (s * s + 1.0) ** 0.5
+    return int(ts[target_step]), init / d, s / d

@@ -53,6 +53,12 @@ def make_context(cfg: UNetConfig, seed: int = 77) -> torch.Tensor:
     return 0.5 * torch.randn((2, cfg.ctx_len, cfg.cross_attention_dim), generator=g)
 
 
+def make_pooled(cfg: UNetConfig, seed: int = 78) -> torch.Tensor:
+    """Stand-in for SDXL's pooled text embeddings [neg, pos]: (2, pooled_dim) fp32."""
+    g = torch.Generator("cpu").manual_seed(seed)
+    return 0.5 * torch.randn((2, cfg.pooled_dim), generator=g)
+
+
 def _lowfreq(g: torch.Generator, ch: int, side: int, normal: bool) -> torch.Tensor:
     base = torch.randn((1, ch, 8, 8), generator=g) if normal else torch.rand((1, ch, 8, 8), generator=g)
     return torch.nn.functional.interpolate(base, size=(side, side), mode="bilinear",

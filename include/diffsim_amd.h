@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSIM_ABI_VERSION 1
+#define DSIM_ABI_VERSION 2
 
 typedef enum dsim_status {
     DSIM_OK = 0,
@@ -63,7 +63,17 @@ typedef struct dsim_unet_cfg {
     int32_t ctx_len;                              /* 77 */
     int32_t compute_dtype;                        /* dsim_dtype: DSIM_F32 (parity mode) or DSIM_BF16 */
     int32_t tap_block;                            /* dsim_tap_block */
-    int32_t tap_layer;                            /* index after the reference's slicing */
+    int32_t tap_layer;                            /* ABSOLUTE index into down_blocks / up_blocks (the wrapper
+                                                     resolves the reference's slices: SD1.5 down[:-1]/up[1:],
+                                                     SDXL down[1:]/up[:-1]); ignored for DSIM_TAP_MID */
+    int32_t tap_attn;                             /* attention index inside the block, -1 = last (SD1.5) */
+    int32_t tap_tfm;                              /* transformer_block index inside it, -1 = last (SD1.5) */
+    /* SDXL deltas; zero = SD1.5 behaviour */
+    int32_t heads_per_level[DSIM_MAX_LEVELS];     /* 5,10,20 ; 0 = num_heads everywhere */
+    int32_t depth_per_level[DSIM_MAX_LEVELS];     /* transformer blocks per Transformer2DModel: 1,2,10 ; 0 = 1 */
+    int32_t addition_embed;                       /* 1: "text_time" added conditioning (add_embedding.*) */
+    int32_t addition_time_embed_dim;              /* 256 */
+    int32_t pooled_dim;                           /* 1280 */
 } dsim_unet_cfg;
 
 typedef struct dsim_unet dsim_unet;
@@ -93,6 +103,11 @@ int  dsim_unet_finalize(dsim_unet* h, void* stream);
  * Pre-computes the time embedding and every ResnetBlock2D time_emb_proj (t is constant over a
  * run).  Enqueues on `stream`. */
 int  dsim_unet_set_timestep(dsim_unet* h, int t, void* stream);
+/* SDXL: timestep plus the added conditioning of DiffSimXLPipeline.step (diffsim/diffsim_xl_pipeline.py:231-262,
+ * 312): text_embeds f32 device [2][pooled_dim] = [negative, positive] pooled prompt embeddings, time_ids f32
+ * device [2][6] = (original_size, crop_top_left, target_size).  The two CFG halves get different time
+ * embeddings; every ResnetBlock2D bias is prepared once per half. */
+int  dsim_unet_set_conditioning(dsim_unet* h, int t, const float* text_embeds, const float* time_ids, void* stream);
 
 size_t dsim_unet_workspace_bytes(const dsim_unet* h, int n_images);
 

@@ -70,10 +70,24 @@ class UNetConfig:
     sample_size: int = 64
     transformer_layers_per_block: int = 1
     ctx_len: int = 77
+    # ---- SDXL deltas; None/False = SD1.5 behaviour ---------------
+    heads_per_level: Optional[Tuple[int, ...]] = None          # (5, 10, 20): head_dim 64
+    depth_per_level: Optional[Tuple[int, ...]] = None          # transformer_layers_per_block (1, 2, 10)
+    use_linear_projection: bool = False
+    addition_embed: bool = False                                # addition_embed_type == "text_time"
+    addition_time_embed_dim: int = 256
+    pooled_dim: int = 1280                                      # text_embeds width (2816 = 1280 + 6*256)
+    sdxl_tap: bool = False                                      # tap addressing of diffsim_xl.py:88-107
 
     @property
     def time_embed_dim(self) -> int:
         return self.block_out_channels[0] * 4
+
+    def heads(self, level: int) -> int:
+        return self.heads_per_level[level] if self.heads_per_level else self.num_attention_heads
+
+    def depth(self, level: int) -> int:
+        return self.depth_per_level[level] if self.depth_per_level else self.transformer_layers_per_block
 
 
 SD15 = UNetConfig()
@@ -81,6 +95,18 @@ SD15 = UNetConfig()
 # straddling concat groups, 8x8 -> 1x1 ... kept >= 2x2 at the bottom) for fast tests
 TINY = UNetConfig(block_out_channels=(64, 128, 256, 256), num_attention_heads=4,
                   cross_attention_dim=128, sample_size=16, ctx_len=13)
+SDXL = UNetConfig(block_out_channels=(320, 640, 1280),
+                  down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                  up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+                  cross_attention_dim=2048, sample_size=128, heads_per_level=(5, 10, 20), depth_per_level=(1, 2, 10),
+                  use_linear_projection=True, addition_embed=True, sdxl_tap=True)
+# same topology (no attention at level 0, depths 1/2/3, linear projections, text_time embedding), small widths
+SDXL_TINY = UNetConfig(block_out_channels=(64, 128, 256),
+                       down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                       up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+                       cross_attention_dim=128, sample_size=16, ctx_len=13, heads_per_level=(1, 2, 4),
+                       depth_per_level=(1, 2, 3), use_linear_projection=True, addition_embed=True,
+                       addition_time_embed_dim=32, pooled_dim=64, sdxl_tap=True)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -327,15 +353,15 @@ class Transformer2DModel(nn.Module):
 # blocks
 # ----------------------------------------------------------------------------------------------
 class CrossAttnDownBlock2D(nn.Module):
-    def __init__(self, cin, cout, cfg: UNetConfig, add_downsample: bool):
+    def __init__(self, cin, cout, cfg: UNetConfig, add_downsample: bool, level: int = 0):
         super().__init__()
         n = cfg.layers_per_block
         self.resnets = nn.ModuleList([
             ResnetBlock2D(cin if i == 0 else cout, cout, cfg.time_embed_dim, cfg.norm_num_groups,
                           cfg.norm_eps) for i in range(n)])
         self.attentions = nn.ModuleList([
-            Transformer2DModel(cout, cfg.num_attention_heads, cfg.cross_attention_dim,
-                               cfg.norm_num_groups, cfg.transformer_layers_per_block)
+            Transformer2DModel(cout, cfg.heads(level), cfg.cross_attention_dim,
+                               cfg.norm_num_groups, cfg.depth(level), cfg.use_linear_projection)
             for _ in range(n)])
         self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if add_downsample else None
         self.has_cross_attention = True
@@ -354,7 +380,7 @@ class CrossAttnDownBlock2D(nn.Module):
 
 
 class DownBlock2D(nn.Module):
-    def __init__(self, cin, cout, cfg: UNetConfig, add_downsample: bool):
+    def __init__(self, cin, cout, cfg: UNetConfig, add_downsample: bool, level: int = 0):
         super().__init__()
         n = cfg.layers_per_block
         self.resnets = nn.ModuleList([
@@ -382,8 +408,9 @@ class UNetMidBlock2DCrossAttn(nn.Module):
             ResnetBlock2D(c, c, cfg.time_embed_dim, cfg.norm_num_groups, cfg.norm_eps)
             for _ in range(2)])
         self.attentions = nn.ModuleList([
-            Transformer2DModel(c, cfg.num_attention_heads, cfg.cross_attention_dim,
-                               cfg.norm_num_groups, cfg.transformer_layers_per_block)])
+            Transformer2DModel(c, cfg.heads(len(cfg.block_out_channels) - 1), cfg.cross_attention_dim,
+                               cfg.norm_num_groups, cfg.depth(len(cfg.block_out_channels) - 1),
+                               cfg.use_linear_projection)])
 
     def forward(self, h, temb, ctx):
         h = self.resnets[0](h, temb)
@@ -404,7 +431,7 @@ def _up_resnets(cin, cout, prev, n, cfg):
 
 
 class UpBlock2D(nn.Module):
-    def __init__(self, cin, cout, prev, cfg: UNetConfig, add_upsample: bool):
+    def __init__(self, cin, cout, prev, cfg: UNetConfig, add_upsample: bool, level: int = 0):
         super().__init__()
         self.resnets = _up_resnets(cin, cout, prev, cfg.layers_per_block + 1, cfg)
         self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_upsample else None
@@ -422,13 +449,13 @@ class UpBlock2D(nn.Module):
 
 
 class CrossAttnUpBlock2D(nn.Module):
-    def __init__(self, cin, cout, prev, cfg: UNetConfig, add_upsample: bool):
+    def __init__(self, cin, cout, prev, cfg: UNetConfig, add_upsample: bool, level: int = 0):
         super().__init__()
         n = cfg.layers_per_block + 1
         self.resnets = _up_resnets(cin, cout, prev, n, cfg)
         self.attentions = nn.ModuleList([
-            Transformer2DModel(cout, cfg.num_attention_heads, cfg.cross_attention_dim,
-                               cfg.norm_num_groups, cfg.transformer_layers_per_block)
+            Transformer2DModel(cout, cfg.heads(level), cfg.cross_attention_dim,
+                               cfg.norm_num_groups, cfg.depth(level), cfg.use_linear_projection)
             for _ in range(n)])
         self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_upsample else None
         self.has_cross_attention = True
@@ -461,13 +488,15 @@ class UNet2DConditionModel(nn.Module):
         ch = cfg.block_out_channels
         self.conv_in = nn.Conv2d(cfg.in_channels, ch[0], 3, padding=1)
         self.time_embedding = TimestepEmbedding(ch[0], cfg.time_embed_dim)
+        if cfg.addition_embed:      # SDXL "text_time": pooled text embeds + 6 sinusoidal time ids
+            self.add_embedding = TimestepEmbedding(cfg.pooled_dim + 6 * cfg.addition_time_embed_dim, cfg.time_embed_dim)
         self.down_blocks = nn.ModuleList()
         out = ch[0]
         for i, typ in enumerate(cfg.down_block_types):
             cin, out = out, ch[i]
             last = i == len(ch) - 1
             cls = CrossAttnDownBlock2D if typ == "CrossAttnDownBlock2D" else DownBlock2D
-            self.down_blocks.append(cls(cin, out, cfg, add_downsample=not last))
+            self.down_blocks.append(cls(cin, out, cfg, add_downsample=not last, level=i))
         self.mid_block = UNetMidBlock2DCrossAttn(ch[-1], cfg)
         self.up_blocks = nn.ModuleList()
         rev = list(reversed(ch))
@@ -477,12 +506,21 @@ class UNet2DConditionModel(nn.Module):
             cin = rev[min(i + 1, len(ch) - 1)]
             last = i == len(ch) - 1
             cls = CrossAttnUpBlock2D if typ == "CrossAttnUpBlock2D" else UpBlock2D
-            self.up_blocks.append(cls(cin, out, prev, cfg, add_upsample=not last))
+            self.up_blocks.append(cls(cin, out, prev, cfg, add_upsample=not last, level=len(ch) - 1 - i))
         self.conv_norm_out = nn.GroupNorm(cfg.norm_num_groups, ch[0], eps=cfg.norm_eps)
         self.conv_out = nn.Conv2d(ch[0], cfg.out_channels, 3, padding=1)
 
     # -- tap selection: diffsim/diffsim.py:122-145 -------------------------------------------
-    def tap_module(self, target_block: str, target_layer: int) -> Attention:
+    def tap_module(self, target_block: str, target_layer) -> Attention:
+        if self.cfg.sdxl_tap:       # diffsim/diffsim_xl.py:88-107: [block, attention, transformer_block]
+            tl = list(target_layer)
+            if target_block == "down_blocks":
+                return self.down_blocks[1:][tl[0]].attentions[tl[1]].transformer_blocks[tl[2]].attn1
+            if target_block == "mid_blocks":
+                return self.mid_block.attentions[tl[0]].transformer_blocks[tl[1]].attn1
+            if target_block == "up_blocks":
+                return self.up_blocks[:-1][tl[0]].attentions[tl[1]].transformer_blocks[tl[2]].attn1
+            raise ValueError(target_block)
         if target_block == "down_blocks":
             blk = self.down_blocks[:-1][target_layer]
         elif target_block == "mid_blocks":
@@ -493,11 +531,15 @@ class UNet2DConditionModel(nn.Module):
             raise ValueError(target_block)
         return blk.attentions[-1].transformer_blocks[-1].attn1
 
-    def forward(self, sample, t, ctx, stats: Optional[dict] = None):
+    def forward(self, sample, t, ctx, stats: Optional[dict] = None, added_cond_kwargs: Optional[dict] = None):
         """Full forward to ``conv_out`` (what diffsim_pipeline.py:213-221 executes)."""
         b = sample.shape[0]
-        tt = torch.full((b,), int(t), dtype=torch.int64)
+        tt = torch.full((b,), float(t), dtype=torch.float32)
         temb = self.time_embedding(timestep_embedding(tt, self.cfg.block_out_channels[0]))
+        if self.cfg.addition_embed:
+            te, ids = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
+            tid = timestep_embedding(ids.flatten().float(), self.cfg.addition_time_embed_dim).reshape(b, -1)
+            temb = temb + self.add_embedding(torch.cat([te.float(), tid], dim=-1))
         h = self.conv_in(sample)
         skips = (h,)
         _rec(stats, "conv_in", h)
@@ -517,7 +559,7 @@ class UNet2DConditionModel(nn.Module):
 
     @torch.no_grad()
     def qkv_at_tap(self, sample, t, ctx, target_block="up_blocks", target_layer=0,
-                   full: bool = False, stats: Optional[dict] = None):
+                   full: bool = False, stats: Optional[dict] = None, added_cond_kwargs: Optional[dict] = None):
         """Run the forward and return q,k,v (B,H,N,D) of the tapped attn1 (diffsim.py:43-56).
 
         ``full=False`` stops right after the tap (no numeric effect on q/k/v: nothing after the
@@ -535,7 +577,7 @@ class UNet2DConditionModel(nn.Module):
 
         hd = mod.register_forward_pre_hook(pre_hook)
         try:
-            self.forward(sample, t, ctx, stats)
+            self.forward(sample, t, ctx, stats, added_cond_kwargs)
         except _TapReached:
             pass
         finally:
@@ -727,3 +769,52 @@ class AutoencoderKLEncoder(nn.Module):
         mean, logvar = self.moments(x).chunk(2, dim=1)
         std = torch.exp(0.5 * logvar.clamp(-30.0, 20.0))
         return mean + std * torch.randn(mean.shape, generator=generator, dtype=mean.dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# SDXL one-step pipeline arithmetic (diffsim/diffsim_xl_pipeline.py:190-323): EulerDiscreteScheduler
+# with SDXL's scheduler_config (scaled_linear betas, timestep_spacing "leading", steps_offset 1).
+# diffusers is not vendored: restated from SURVEY.md Appendix A item 14 -- PARITY UNPINNED.
+# ----------------------------------------------------------------------------------------------
+def euler_tables(num_inference_steps: int = 1000, num_train_timesteps: int = 1000, steps_offset: int = 1):
+    """-> (timesteps float32 [N], sigmas float32 [N+1], init_noise_sigma)."""
+    ac = alphas_cumprod().numpy().astype(np.float64)
+    sig_all = ((1 - ac) / ac) ** 0.5
+    ratio = num_train_timesteps // num_inference_steps
+    ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.float32) + steps_offset
+    sig = np.interp(ts, np.arange(0, len(sig_all)), sig_all)
+    sig = np.concatenate([sig, [0.0]]).astype(np.float32)
+    init = float((sig.max() ** 2 + 1) ** 0.5)      # "leading" spacing
+    return ts, sig, init
+
+
+def sdxl_inputs(z0: torch.Tensor, noise: torch.Tensor, target_step: int):
+    """Reference quirk reproduced (diffsim_xl_pipeline.py:204-225, 309): the CLEAN latents are
+    multiplied by init_noise_sigma, then sigma*noise is added, then the sum is divided by
+    sqrt(sigma^2+1).  Returns (x_in, t)."""
+    ts, sig, init = euler_tables()
+    t, s = float(ts[target_step]), float(sig[target_step])
+    x = z0 * init + noise * s
+    return x / ((s * s + 1) ** 0.5), t
+
+
+def sdxl_time_ids(cfg: UNetConfig) -> torch.Tensor:
+    side = float(cfg.sample_size * 8)      # height/width default to sample_size * vae_scale_factor
+    return torch.tensor([[side, side, 0.0, 0.0, side, side]], dtype=torch.float32)
+
+
+@torch.no_grad()
+def features_xl(unet: UNet2DConditionModel, z0, noise, ctx, pooled, target_step, target_block, target_layer, full=False):
+    """z0, noise (1,4,h,w); ctx (2,L,Dc) = [neg, pos]; pooled (2,P) = [neg, pos] -> q,k,v (2,H,N,D)."""
+    x, t = sdxl_inputs(z0, noise, target_step)
+    xin = torch.cat([x] * 2)
+    added = {"text_embeds": pooled, "time_ids": sdxl_time_ids(unet.cfg).repeat(2, 1)}
+    return unet.qkv_at_tap(xin, t, ctx, target_block, target_layer, full=full, added_cond_kwargs=added)
+
+
+@torch.no_grad()
+def diffsim_xl_latents(unet, zA, zB, nA, nB, ctx, pooled, target_step, target_block, target_layer,
+                       similarity="cosine", full=False):
+    a = features_xl(unet, zA, nA, ctx, pooled, target_step, target_block, target_layer, full)
+    b = features_xl(unet, zB, nB, ctx, pooled, target_step, target_block, target_layer, full)
+    return pair_score(*a, *b, similarity)

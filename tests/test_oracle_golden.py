@@ -159,3 +159,20 @@ def test_oracle_properties(tiny):
     assert abs(float(s_ab) - float(s_ba)) > 1e-6    # symmetric only up to slot noise
     s_swap = R.diffsim_latents(unet, zB, zA, n[3], n[2], ctx)
     assert abs(float(s_ab) - float(s_swap)) < 1e-6  # swapping images AND their noise is symmetric
+
+
+def test_g8_sdxl_reference_orchestration():
+    """Scores the reference's diffsim_xl.py + diffsim_xl_pipeline.py produced on the oracle's SDXL-topology
+    U-Net must be reproduced by the oracle's own SDXL pipeline restatement (Euler quirks included)."""
+    import ast
+    g = np.load(os.path.join(G, "g8_sdxl_tiny.npz"))
+    sd = S.make_state_dict(C.SDXL_TINY, seed=0)
+    unet = R.build_unet(R.SDXL_TINY, sd)
+    ctx, pooled = S.make_context(C.SDXL_TINY), S.make_pooled(C.SDXL_TINY)
+    zA, zB, nA, nB = (torch.from_numpy(g[k]) for k in ("latA", "latB", "noiseA", "noiseB"))
+    for ci in range(6):
+        blk, tl, step, sim = (str(x) for x in g[f"case_{ci}"])
+        s = R.diffsim_xl_latents(unet, zA, zB, nA, nB, ctx, pooled, int(step), blk, ast.literal_eval(tl), sim)
+        np.testing.assert_allclose(s.numpy().reshape(-1), g[f"score_{ci}"], rtol=2e-5, atol=1e-6)
+    shapes = C.unet_param_shapes(C.SDXL)
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 2_567_463_684      # SDXL base U-Net parameter count

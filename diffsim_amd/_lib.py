@@ -48,6 +48,11 @@ class VAECfgC(C.Structure):
     ]
 
 
+class DiTCfgC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("input_size", "patch_size", "in_channels", "hidden_size", "depth", "num_heads",
+                                          "mlp_ratio", "num_classes", "freq_dim", "compute_dtype", "tap_layer")]
+
+
 # every symbol include/diffsim_amd.h declares: (restype, argtypes)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SYMBOLS = {
@@ -73,6 +78,13 @@ SYMBOLS = {
     "dsim_vae_finalize": (_i, [_vp, _vp]),
     "dsim_vae_workspace_bytes": (_sz, [_vp, _i, _i]),
     "dsim_vae_encode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "dsim_dit_create": (_i, [C.POINTER(DiTCfgC), C.POINTER(_vp)]),
+    "dsim_dit_destroy": (None, [_vp]),
+    "dsim_dit_load_weight": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(C.c_int64), _i]),
+    "dsim_dit_finalize": (_i, [_vp, _vp]),
+    "dsim_dit_set_conditioning": (_i, [_vp, _i, _i, _i, _vp]),
+    "dsim_dit_workspace_bytes": (_sz, [_vp, _i]),
+    "dsim_dit_qkv": (_i, [_vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dsim_pair_score_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "dsim_pair_score": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "dsim_op_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

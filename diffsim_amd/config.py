@@ -238,3 +238,49 @@ def vae_encoder_param_shapes(cfg: VAEConfig) -> Dict[str, Tuple[int, ...]]:
     out["quant_conv.weight"] = (m, m, 1, 1)
     out["quant_conv.bias"] = (m,)
     return out
+
+
+@dataclass(frozen=True)
+class DiTConfig:
+    """DiT-XL/2 as instantiated by the reference (diffsim/diffsim_dit.py:31-35, DiT/modelsdit.py:147-176)."""
+    input_size: int = 32            # latent side (256 px / 8)
+    patch_size: int = 2
+    in_channels: int = 4
+    hidden_size: int = 1152
+    depth: int = 28
+    num_heads: int = 16
+    mlp_ratio: int = 4
+    num_classes: int = 1000
+    freq_dim: int = 256
+
+
+DIT_XL2 = DiTConfig()
+DIT_TINY = DiTConfig(input_size=16, hidden_size=128, depth=3, num_heads=4)
+
+
+def dit_param_shapes(cfg: DiTConfig) -> Dict[str, Tuple[int, ...]]:
+    """Parameters of DiT up to the last block (final_layer is never needed), reference key names."""
+    d, p = cfg.hidden_size, cfg.patch_size
+    t = (cfg.input_size // p) ** 2
+    out: Dict[str, Tuple[int, ...]] = {}
+    out["pos_embed"] = (1, t, d)
+    out["x_embedder.proj.weight"] = (d, cfg.in_channels, p, p)
+    out["x_embedder.proj.bias"] = (d,)
+    out["t_embedder.mlp.0.weight"] = (d, cfg.freq_dim)
+    out["t_embedder.mlp.0.bias"] = (d,)
+    out["t_embedder.mlp.2.weight"] = (d, d)
+    out["t_embedder.mlp.2.bias"] = (d,)
+    out["y_embedder.embedding_table.weight"] = (cfg.num_classes + 1, d)
+    for i in range(cfg.depth):
+        b = f"blocks.{i}."
+        out[b + "attn.qkv.weight"] = (3 * d, d)
+        out[b + "attn.qkv.bias"] = (3 * d,)
+        out[b + "attn.proj.weight"] = (d, d)
+        out[b + "attn.proj.bias"] = (d,)
+        out[b + "mlp.fc1.weight"] = (cfg.mlp_ratio * d, d)
+        out[b + "mlp.fc1.bias"] = (cfg.mlp_ratio * d,)
+        out[b + "mlp.fc2.weight"] = (d, cfg.mlp_ratio * d)
+        out[b + "mlp.fc2.bias"] = (d,)
+        out[b + "adaLN_modulation.1.weight"] = (6 * d, d)
+        out[b + "adaLN_modulation.1.bias"] = (6 * d,)
+    return out

@@ -49,6 +49,9 @@ struct GemmArgs {
     const float* bias = nullptr;                // [N] f32 (packed order) or null
     const float* bias2 = nullptr;               // optional: bias of ODD batch elements (m / rows_per_batch) & 1 -- SDXL's
     int rows_per_batch = 0;                     //   time embedding differs between the uncond/cond CFG halves
+    int act = 0;                                // 1: tanh-GELU after the bias (DiT Mlp.fc1)
+    const float* gate = nullptr;                // optional per-column scale applied before the residual add (DiT adaLN
+    const float* gate2 = nullptr;               //   gates); gate2 = the ODD batch elements' vector
     int epi = EPI_NONE;
     const void* residual = nullptr;             // [M][ldo]
     void* out = nullptr;
@@ -89,6 +92,10 @@ int launch_groupnorm(const void* x0, int C0, const void* x1, int C1, const float
                      int dtype, void* scratch, hipStream_t s);
 int launch_layernorm(const void* x, const float* gamma, const float* beta, void* out, int M, int C,
                      float eps, int dtype, hipStream_t s);
+// LayerNorm without affine followed by adaLN modulate: y = LN(x) * (1 + scale[half]) + shift[half], half =
+// (row / rows_per_batch) & 1 (DiT blocks; scale/shift are f32 [2][C])
+int launch_layernorm_mod(const void* x, const float* scale2, const float* shift2, void* out, int M, int C,
+                         int rows_per_batch, float eps, int dtype, hipStream_t s);
 // out[r][:] = softmax(x[r][:] * scale) over `cols` (VAE mid-block attention; in place allowed)
 int launch_softmax_rows(const void* x, void* out, int rows, int cols, float scale, int dtype, hipStream_t s);
 

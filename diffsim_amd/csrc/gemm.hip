@@ -381,6 +381,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                         for (int f = 0; f < 4; ++f) v[e + f] += b4[f];
                     }
                 }
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {      // tanh-GELU: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+                        const float x = v[e], u = 0.7978845608028654f * fmaf(0.044715f * x * x, x, x);
+                        const float ex = __builtin_amdgcn_exp2f(2.8853900817779268f * u);      // e^(2u)
+                        v[e] = 0.5f * x * (1.0f + (1.0f - 2.0f / (ex + 1.0f)));
+                    }
+                }
+                if (p.gate) {
+                    const float* gsel = (p.gate2 && ((m / p.rows_per_batch) & 1)) ? p.gate2 : p.gate;
+#pragma unroll
+                    for (int e = 0; e < VEC; e += 4) {
+                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gsel + nout0 + ncol + e);
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) v[e + f] *= g4[f];
+                    }
+                }
                 if (p.epi == EPI_RESIDUAL) {
                     if constexpr (sizeof(T) == 2) {
                         const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(res + o);

@@ -182,10 +182,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
 }
 
 // one wave per row; 4 rows per workgroup
-template <typename T>
+// MOD: no affine; y = xhat * (1 + scale[half][c]) + shift[half][c] with gamma = scale, beta = shift, [2][C] each
+template <typename T, bool MOD = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ out,
-                                                        int M, int C, float eps) {
+                                                        int M, int C, float eps, int rows_per_batch = 1) {
     constexpr int VEC = Vec16<T>::N;
     constexpr int MAXS = 6;                 // C <= 64*6*VEC (3072 bf16 / 1536 f32)
     typedef typename Vec16<T>::type V;
@@ -232,7 +233,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const int c = slot * VEC + e;
-                o[e] = (T)fmaf((v[k][e] - mean) * rstd, gamma[c], beta[c]);
+                if (MOD) {
+                    const int hoff = ((row / rows_per_batch) & 1) * C;
+                    o[e] = (T)fmaf((v[k][e] - mean) * rstd, 1.0f + gamma[hoff + c], beta[hoff + c]);
+                } else {
+                    o[e] = (T)fmaf((v[k][e] - mean) * rstd, gamma[c], beta[c]);
+                }
             }
             *reinterpret_cast<V*>(orow + slot * VEC) = o;
         }
@@ -333,9 +339,24 @@ int launch_layernorm(const void* x, const float* gamma, const float* beta, void*
     if (C % vec || C > 64 * 6 * vec) return DSIM_ERR_INVALID;
     const dim3 grid((M + 3) / 4), block(256);
     if (dtype == DSIM_BF16)
-        hipLaunchKernelGGL(layernorm_kernel<bf16>, grid, block, 0, s, (const bf16*)x, gamma, beta, (bf16*)out, M, C, eps);
+        hipLaunchKernelGGL((layernorm_kernel<bf16, false>), grid, block, 0, s, (const bf16*)x, gamma, beta, (bf16*)out, M, C, eps, 1);
     else if (dtype == DSIM_F32)
-        hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, s, (const float*)x, gamma, beta, (float*)out, M, C, eps);
+        hipLaunchKernelGGL((layernorm_kernel<float, false>), grid, block, 0, s, (const float*)x, gamma, beta, (float*)out, M, C, eps, 1);
+    else
+        return DSIM_ERR_INVALID;
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+
+int launch_layernorm_mod(const void* x, const float* scale2, const float* shift2, void* out, int M, int C,
+                         int rows_per_batch, float eps, int dtype, hipStream_t s) {
+    const int vec = dtype == DSIM_F32 ? 4 : 8;
+    if (C % vec || C > 64 * 6 * vec || rows_per_batch < 1) return DSIM_ERR_INVALID;
+    const dim3 grid((M + 3) / 4), block(256);
+    if (dtype == DSIM_BF16)
+        hipLaunchKernelGGL((layernorm_kernel<bf16, true>), grid, block, 0, s, (const bf16*)x, scale2, shift2, (bf16*)out, M, C, eps, rows_per_batch);
+    else if (dtype == DSIM_F32)
+        hipLaunchKernelGGL((layernorm_kernel<float, true>), grid, block, 0, s, (const float*)x, scale2, shift2, (float*)out, M, C, eps, rows_per_batch);
     else
         return DSIM_ERR_INVALID;
     DSIM_HIP_CHECK(hipGetLastError());

@@ -107,7 +107,18 @@ static inline int pack_all(WeightStore* h, hipStream_t s) {
         const std::string& key = kv.first;
         const RawW& w = kv.second;
         Packed P;
-        if (w.shape.size() == 1) {
+        const bool keep_f32 = key == "pos_embed" || ends_with(key, "x_embedder.proj.weight") ||
+                              ends_with(key, "embedding_table.weight") || key.rfind("t_embedder.", 0) == 0 ||
+                              ends_with(key, "adaLN_modulation.1.weight");
+        if (keep_f32 && w.shape.size() >= 2) {
+            // small DiT conditioning tensors consumed by f32 GEMV / lookup / patch-embed kernels: flat f32 copy
+            int64_t n = 1;
+            for (auto d : w.shape) n *= d;
+            CK(h->dalloc((size_t)n * 4, &P.p));
+            P.rows = (int)w.shape[0]; P.cols = (int)(n / w.shape[0]); P.bytes = (size_t)n * 4;
+            CK(pack_vector(w.p, w.dtype, (float*)P.p, (int)n, 0, s));
+            h->pk[key] = P;
+        } else if (w.shape.size() == 1) {
             const int n = (int)w.shape[0];
             const int geglu = ends_with(key, "ff.net.0.proj.bias");
             CK(h->dalloc((size_t)n * 4, &P.p));

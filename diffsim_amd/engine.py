@@ -373,3 +373,75 @@ class VAEEncoder:
 
     def encode(self, images: torch.Tensor) -> _EncodeOut:
         return _EncodeOut(self.moments(images))
+
+
+# ---- DiT backbone ---------------------------------------------------------
+class DiTEngine:
+    """One handle = (DiT config, compute dtype, tapped block)."""
+
+    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], dtype: torch.dtype = torch.bfloat16, target_layer: int = 0,
+                 device: str = "cuda:0"):
+        self.L = _lib.lib()
+        if not torch.cuda.is_available():
+            raise _lib.DsimError("no GPU visible: the DiT engine runs only on the HIP device")
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        c = _lib.DiTCfgC()
+        for f in ("input_size", "patch_size", "in_channels", "hidden_size", "depth", "num_heads", "mlp_ratio", "num_classes",
+                  "freq_dim"):
+            setattr(c, f, getattr(cfg, f))
+        c.compute_dtype, c.tap_layer = _TORCH2DSIM[dtype], int(target_layer)
+        self.tokens = (cfg.input_size // cfg.patch_size) ** 2
+        self.heads, self.head_dim = cfg.num_heads, cfg.hidden_size // cfg.num_heads
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.dsim_dit_create(C.byref(c), C.byref(self._h)), "dsim_dit_create")
+            keep = []
+            for k, v in state_dict.items():
+                if k.startswith("final_layer"):
+                    continue
+                t = v.detach()
+                if t.dtype not in _TORCH2DSIM:
+                    t = t.float()
+                t = t.to(self.device).contiguous()
+                keep.append(t)
+                shp = (C.c_int64 * t.ndim)(*t.shape)
+                _lib.check(self.L.dsim_dit_load_weight(self._h, k.encode(), t.data_ptr(), _TORCH2DSIM[t.dtype], shp, t.ndim),
+                           f"dit load_weight({k})")
+            torch.cuda.synchronize(self.device)
+            _lib.check(self.L.dsim_dit_finalize(self._h, _stream_ptr()), "dsim_dit_finalize")
+            del keep
+        self._ws = None
+        self._cond = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self.L.dsim_dit_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def set_conditioning(self, t_model: int, y0: int, y1: int):
+        if self._cond != (t_model, y0, y1):
+            with torch.cuda.device(self.device):
+                _lib.check(self.L.dsim_dit_set_conditioning(self._h, int(t_model), int(y0), int(y1), _stream_ptr()),
+                           "dit set_conditioning")
+            self._cond = (t_model, y0, y1)
+
+    def qkv(self, latents: torch.Tensor, noise: torch.Tensor, sa: float, sb: float):
+        _require_cuda(latents, noise)
+        n = latents.shape[0]
+        s = self.cfg.input_size
+        if tuple(latents.shape) != (n, self.cfg.in_channels, s, s) or latents.dtype != torch.float32 or noise.shape != latents.shape:
+            raise _lib.DsimError(f"latents/noise must be float32 (n,{self.cfg.in_channels},{s},{s})")
+        with torch.cuda.device(self.device):
+            need = int(self.L.dsim_dit_workspace_bytes(self._h, n))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = None
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            shape = (n, 2, self.tokens, self.cfg.hidden_size)
+            q, k, v = (torch.empty(shape, dtype=self.dtype, device=self.device) for _ in range(3))
+            _lib.check(self.L.dsim_dit_qkv(self._h, latents.data_ptr(), noise.data_ptr(), float(sa), float(sb), n, q.data_ptr(),
+                                           k.data_ptr(), v.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _stream_ptr()),
+                       "dsim_dit_qkv")
+        return q, k, v

@@ -64,3 +64,23 @@ def sdxl_step_coefficients(target_step: int):
     s = float(sig[target_step])
     d = (s * s + 1.0) ** 0.5
     return int(ts[target_step]), init / d, s / d
+
+
+# ---- DiT: timestep respacing of the vendored OpenAI-style diffusion ------------------------------------
+def dit_timestep_map(target_step: int, num_timesteps: int = 1000):
+    """``create_diffusion(str(target_step)).timestep_map`` (DiT/diffusion/respace.py:12-88): target_step
+    evenly spaced original timesteps, as a sorted list."""
+    n = int(target_step)
+    stride = 1 if n <= 1 else (num_timesteps - 1) / (n - 1)
+    return sorted({round(i * stride) for i in range(n)})
+
+
+def dit_model_timestep(target_step: int) -> int:
+    """The model is called with t = 1000 - target_step remapped through the spaced schedule
+    (diffsim/diffsim_dit.py:105; respace.py:117-129) -- noise is added at t = target_step but the network is
+    conditioned on timestep_map[1000 - target_step] (quirk reproduced; needs target_step > 500)."""
+    m = dit_timestep_map(target_step)
+    i = 1000 - int(target_step)
+    if not 0 <= i < len(m):
+        raise IndexError(f"target_step {target_step}: index {i} outside the {len(m)}-entry spaced schedule")
+    return int(m[i])

@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from .config import UNetConfig, VAEConfig, unet_param_shapes, vae_encoder_param_shapes
+from .config import DiTConfig, UNetConfig, VAEConfig, dit_param_shapes, unet_param_shapes, vae_encoder_param_shapes
 
 
 def make_state_dict(cfg: UNetConfig, seed: int = 0, keys: Optional[Sequence[str]] = None
@@ -22,7 +22,10 @@ def make_state_dict(cfg: UNetConfig, seed: int = 0, keys: Optional[Sequence[str]
     1.4 so attention logits have std ~2 (non-degenerate softmax; SURVEY.md section 7 "hard parts");
     norm affine parameters are perturbed away from (1,0) so a dropped gamma/beta is caught.
     Each tensor has its own generator keyed by its position, so a subset is reproducible."""
-    shapes = vae_encoder_param_shapes(cfg) if isinstance(cfg, VAEConfig) else unet_param_shapes(cfg)
+    if isinstance(cfg, DiTConfig):
+        shapes = dit_param_shapes(cfg)
+    else:
+        shapes = vae_encoder_param_shapes(cfg) if isinstance(cfg, VAEConfig) else unet_param_shapes(cfg)
     out: Dict[str, torch.Tensor] = {}
     for idx, (k, shp) in enumerate(shapes.items()):
         if keys is not None and k not in keys:
@@ -30,6 +33,13 @@ def make_state_dict(cfg: UNetConfig, seed: int = 0, keys: Optional[Sequence[str]
         g = torch.Generator("cpu").manual_seed(seed * 1000003 + idx)
         leaf = k.rsplit(".", 2)
         is_norm = ".norm" in k or "conv_norm_out" in k or "group_norm" in k
+        if k == "pos_embed":
+            out[k] = dit_pos_embed(shp[2], int(round(shp[1] ** 0.5)))
+            continue
+        if k.endswith("adaLN_modulation.1.weight") or k.endswith("embedding_table.weight"):
+            t = 0.3 * torch.randn(shp, generator=g) / (1.0 if k.endswith("table.weight") else math.sqrt(shp[1] / 8.0))
+            out[k] = t.to(torch.float32).contiguous()
+            continue
         if is_norm and k.endswith(".weight"):
             t = 1.0 + 0.1 * torch.randn(shp, generator=g)
         elif is_norm and k.endswith(".bias"):
@@ -100,3 +110,17 @@ def make_image_pair(pair_index: int, size: int = 512, base_seed: int = 1234) -> 
         img = torch.round(0.5 * hf + 0.5 * lf).clamp(0, 255) / 255.0
         outs.append((img - 0.5) / 0.5)
     return outs[0], outs[1]
+
+
+def dit_pos_embed(dim: int, grid: int) -> torch.Tensor:
+    """2-D sin/cos positional table of DiT (DiT/modelsdit.py:278-325; a fixed buffer, part of the state dict)."""
+    import numpy as np
+
+    def one_d(d, pos):
+        omega = 1.0 / 10000 ** (np.arange(d // 2, dtype=np.float64) / (d / 2.0))
+        o = np.einsum("m,d->md", pos.reshape(-1), omega)
+        return np.concatenate([np.sin(o), np.cos(o)], axis=1)
+    gh = np.arange(grid, dtype=np.float32)
+    g = np.stack(np.meshgrid(gh, gh), axis=0).reshape(2, 1, grid, grid)
+    emb = np.concatenate([one_d(dim // 2, g[0]), one_d(dim // 2, g[1])], axis=1)
+    return torch.from_numpy(emb).float().unsqueeze(0).contiguous()

@@ -175,6 +175,39 @@ size_t dsim_vae_workspace_bytes(const dsim_vae* h, int n_images, int image_size)
 int    dsim_vae_encode(dsim_vae* h, const float* images, int n_images, int image_size, float* moments,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- DiT-XL/2 scorer backbone: replaces `diffusion.p_sample(model, latents, t,
+ *      model_kwargs=dict(y=[1, 1000]))` + the pre-hook on model.blocks[L].attn of diffsim/diffsim_dit.py:93-114.
+ *      Weights under the reference's own state-dict keys (DiT/modelsdit.py): pos_embed, x_embedder.proj.*,
+ *      t_embedder.mlp.{0,2}.*, y_embedder.embedding_table.weight, blocks.N.{attn.qkv,attn.proj,mlp.fc1,mlp.fc2,
+ *      adaLN_modulation.1}.* -------------------------------------------------------------------------------- */
+typedef struct dsim_dit_cfg {
+    int32_t input_size;        /* latent side: 32 for 256 px */
+    int32_t patch_size;        /* 2 */
+    int32_t in_channels;       /* 4 */
+    int32_t hidden_size;       /* 1152 */
+    int32_t depth;             /* 28 */
+    int32_t num_heads;         /* 16 */
+    int32_t mlp_ratio;         /* 4 */
+    int32_t num_classes;       /* 1000 (embedding table has num_classes + 1 rows) */
+    int32_t freq_dim;          /* 256 */
+    int32_t compute_dtype;     /* DSIM_F32 or DSIM_BF16 */
+    int32_t tap_layer;         /* block index L of the hooked attention */
+} dsim_dit_cfg;
+typedef struct dsim_dit dsim_dit;
+
+int    dsim_dit_create(const dsim_dit_cfg* cfg, dsim_dit** out);
+void   dsim_dit_destroy(dsim_dit* h);
+int    dsim_dit_load_weight(dsim_dit* h, const char* key, const void* dev_ptr, int dtype, const int64_t* shape, int ndim);
+int    dsim_dit_finalize(dsim_dit* h, void* stream);
+/* t_model = the timestep the MODEL sees = SpacedDiffusion.timestep_map[1000 - target_step]
+ * (DiT/diffusion/respace.py:117-129); y0,y1 = class labels of the two batch halves (1 and num_classes = null) */
+int    dsim_dit_set_conditioning(dsim_dit* h, int t_model, int y0, int y1, void* stream);
+size_t dsim_dit_workspace_bytes(const dsim_dit* h, int n_images);
+/* x_t = sqrt_abar*latents + sqrt_1m_abar*noise (DDIM add_noise at t = target_step, diffsim_dit.py:63-72);
+ * q,k,v (out): compute dtype [n_images][2][tokens][heads*head_dim] */
+int    dsim_dit_qkv(dsim_dit* h, const float* latents, const float* noise, float sqrt_abar, float sqrt_1m_abar,
+                    int n_images, void* q, void* k, void* v, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- single-operator entry points (kernel-level parity tests and micro-benchmarks) -----
  * x: dtype [M][K] (or NHWC image for the conv forms); w: diffusers-layout f32 weight.      */
 int dsim_op_linear(const void* x, const float* w /*[N][K]*/, const float* bias /*[N] or NULL*/,

@@ -818,3 +818,148 @@ def diffsim_xl_latents(unet, zA, zB, nA, nB, ctx, pooled, target_step, target_bl
     a = features_xl(unet, zA, nA, ctx, pooled, target_step, target_block, target_layer, full)
     b = features_xl(unet, zB, nB, ctx, pooled, target_step, target_block, target_layer, full)
     return pair_score(*a, *b, similarity)
+
+
+# ----------------------------------------------------------------------------------------------
+# DiT-XL/2 path: diffsim/diffsim_dit.py:74-142 on DiT/modelsdit.py.
+# The model file is in the reference (restated here from DiT/modelsdit.py:20-21,28-66,103-124,147-250,
+# 278-325 with timm's Attention / Mlp / PatchEmbed semantics, which are NOT vendored); the timestep
+# respacing follows DiT/diffusion/respace.py:12-129 and is pinned by fixture G7.
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class DiTConfig:
+    input_size: int = 32            # latent side (256 px / 8)
+    patch_size: int = 2
+    in_channels: int = 4
+    hidden_size: int = 1152
+    depth: int = 28
+    num_heads: int = 16
+    mlp_ratio: int = 4
+    num_classes: int = 1000
+    freq_dim: int = 256
+
+
+DIT_XL2 = DiTConfig()
+DIT_TINY = DiTConfig(input_size=16, hidden_size=128, depth=3, num_heads=4)
+
+
+def dit_pos_embed(dim: int, grid: int) -> torch.Tensor:
+    """get_2d_sincos_pos_embed (DiT/modelsdit.py:278-325): (1, grid*grid, dim) f32."""
+    def one_d(d, pos):
+        omega = 1.0 / 10000 ** (np.arange(d // 2, dtype=np.float64) / (d / 2.0))
+        out = np.einsum("m,d->md", pos.reshape(-1), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+    gh = np.arange(grid, dtype=np.float32)
+    g = np.stack(np.meshgrid(gh, gh), axis=0).reshape(2, 1, grid, grid)      # w first
+    emb = np.concatenate([one_d(dim // 2, g[0]), one_d(dim // 2, g[1])], axis=1)
+    return torch.from_numpy(emb).float().unsqueeze(0)
+
+
+def dit_timestep_map(target_step: int, num_timesteps: int = 1000):
+    """SpacedDiffusion(space_timesteps(1000, str(target_step))).timestep_map (respace.py:12-88)."""
+    n = int(target_step)
+    stride = 1 if n <= 1 else (num_timesteps - 1) / (n - 1)
+    return sorted({round(i * stride) for i in range(n)})
+
+
+class _DiTAttention(nn.Module):          # timm Attention: fused qkv with bias, identity q/k norm
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads, self.head_dim = heads, dim // heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+        self.q_norm, self.k_norm = nn.Identity(), nn.Identity()
+
+    def split(self, x):
+        b, n, c = x.shape
+        qkv = self.qkv(x).reshape(b, n, 3, self.num_heads, self.head_dim).permute(2, 0, 3, 1, 4)
+        return qkv.unbind(0)
+
+    def forward(self, x):
+        b, n, c = x.shape
+        q, k, v = self.split(x)
+        o = F.scaled_dot_product_attention(q, k, v)
+        return self.proj(o.transpose(1, 2).reshape(b, n, c))
+
+
+class _DiTMlp(nn.Module):                # timm Mlp with tanh-GELU
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1, self.fc2 = nn.Linear(dim, hidden), nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x), approximate="tanh"))
+
+
+class _DiTBlock(nn.Module):
+    def __init__(self, dim, heads, ratio):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+        self.attn = _DiTAttention(dim, heads)
+        self.norm2 = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+        self.mlp = _DiTMlp(dim, dim * ratio)
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(dim, 6 * dim))
+
+    def forward(self, x, c):
+        sm, cm, gm, sl, cl, gl = self.adaLN_modulation(c).chunk(6, dim=1)
+        x = x + gm.unsqueeze(1) * self.attn(self.norm1(x) * (1 + cm.unsqueeze(1)) + sm.unsqueeze(1))
+        x = x + gl.unsqueeze(1) * self.mlp(self.norm2(x) * (1 + cl.unsqueeze(1)) + sl.unsqueeze(1))
+        return x
+
+
+class _TEmb(nn.Module):
+    def __init__(self, dim, fdim):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(fdim, dim), nn.SiLU(), nn.Linear(dim, dim))
+        self.fdim = fdim
+
+    def forward(self, t):
+        half = self.fdim // 2
+        freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+        args = t[:, None].float() * freqs[None]
+        return self.mlp(torch.cat([torch.cos(args), torch.sin(args)], dim=-1))
+
+
+class DiTOracle(nn.Module):
+    def __init__(self, cfg: DiTConfig = DIT_XL2):
+        super().__init__()
+        self.cfg = cfg
+        d, p = cfg.hidden_size, cfg.patch_size
+        self.x_embedder = nn.Module()
+        self.x_embedder.proj = nn.Conv2d(cfg.in_channels, d, p, stride=p)
+        self.t_embedder = _TEmb(d, cfg.freq_dim)
+        self.y_embedder = nn.Module()
+        self.y_embedder.embedding_table = nn.Embedding(cfg.num_classes + 1, d)
+        g = cfg.input_size // p
+        self.pos_embed = nn.Parameter(dit_pos_embed(d, g), requires_grad=False)
+        self.blocks = nn.ModuleList([_DiTBlock(d, cfg.num_heads, cfg.mlp_ratio) for _ in range(cfg.depth)])
+
+    @torch.no_grad()
+    def qkv_at(self, x, t_model: int, y, layer: int):
+        """x (1,C,H,W); y (2,) class ids -> q,k,v (2,H,N,D) = inputs of blocks[layer].attn (diffsim_dit.py:19-26)."""
+        h = self.x_embedder.proj(x).flatten(2).transpose(1, 2) + self.pos_embed
+        c = self.t_embedder(torch.tensor([float(t_model)])) + self.y_embedder.embedding_table(y)
+        for i, blk in enumerate(self.blocks):
+            if i == layer:
+                sm, cm = blk.adaLN_modulation(c).chunk(6, dim=1)[:2]
+                return blk.attn.split(blk.norm1(h) * (1 + cm.unsqueeze(1)) + sm.unsqueeze(1))
+            h = blk(h, c)
+        raise IndexError(layer)
+
+
+@torch.no_grad()
+def dit_features(model: DiTOracle, z0, noise, target_step: int, layer: int):
+    """diffsim_dit.py:87-114: noise at t = target_step with the SD1.5 DDIM alphas, model conditioned on
+    timestep_map[1000 - target_step], labels [1, num_classes] (class 1 + null)."""
+    ac = alphas_cumprod()
+    xt = ac[target_step] ** 0.5 * z0 + (1 - ac[target_step]) ** 0.5 * noise
+    tm = dit_timestep_map(target_step)[1000 - target_step]
+    y = torch.tensor([1, model.cfg.num_classes])
+    return model.qkv_at(xt, tm, y, layer)
+
+
+@torch.no_grad()
+def diffsim_dit_latents(model, zA, zB, nA, nB, target_step, layer, similarity="cosine"):
+    a = dit_features(model, zA, nA, target_step, layer)
+    b = dit_features(model, zB, nB, target_step, layer)
+    return pair_score(*a, *b, similarity)

@@ -176,3 +176,25 @@ def test_g8_sdxl_reference_orchestration():
         np.testing.assert_allclose(s.numpy().reshape(-1), g[f"score_{ci}"], rtol=2e-5, atol=1e-6)
     shapes = C.unet_param_shapes(C.SDXL)
     assert sum(int(np.prod(s)) for s in shapes.values()) == 2_567_463_684      # SDXL base U-Net parameter count
+
+
+def test_g9_dit_reference_model():
+    """The oracle's DiT restatement vs the reference's own diffsim_dit.py + DiT/modelsdit.py run in fp16
+    (the reference hard-codes half precision): scores and q/k/v agree to fp16 rounding."""
+    from diffsim_amd import scheduler as sch
+    g = np.load(os.path.join(G, "g9_dit_tiny.npz"))
+    sd = S.make_state_dict(C.DIT_TINY, seed=0)
+    m = R.DiTOracle(R.DIT_TINY)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    zA, zB, nA, nB = (torch.from_numpy(g[k]) for k in ("latA", "latB", "noiseA", "noiseB"))
+    for ci in range(4):
+        layer, step, sim = (str(x) for x in g[f"case_{ci}"])
+        s = float(R.diffsim_dit_latents(m, zA, zB, nA, nB, int(step), int(layer), sim))
+        assert abs(s - float(g[f"score_{ci}"][0])) <= 2e-3 * max(abs(s), 0.05)
+    q, _, _ = R.dit_features(m, zB, nB, 600, 2)
+    assert (q - torch.from_numpy(g["qB"])).abs().max() <= 4e-3 * q.abs().max()
+    g7 = json.load(open(os.path.join(G, "g7_sched.json")))
+    assert sch.dit_timestep_map(600)[400] == g7["dit_map_400"] == R.dit_timestep_map(600)[400] == 667
+    assert sch.dit_model_timestep(600) == 667 and len(sch.dit_timestep_map(600)) == g7["dit_map_len"]
+    assert sum(int(np.prod(s)) for s in C.dit_param_shapes(C.DIT_XL2).values()) == 672_436_224

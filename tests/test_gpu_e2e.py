@@ -212,3 +212,30 @@ def test_triplet_harness_matches_pairwise_calls(tiny_env, golden_dir, tmp_path):
     pl = ds.score_latent_pairs(ref, left, n[2], n[3], ctx)
     pr = ds.score_latent_pairs(ref, right, n[2], n[3], ctx)
     assert torch.equal(sl, pl) and torch.equal(sr, pr)
+
+
+def test_sd15_full_size_fp32_and_bf16_pairs():
+    """BASELINE config 1 shape: the real SD1.5 graph at 512 px (64x64 latents, 256-token tap, 8 heads x 160),
+    synthetic pairs, fp32 kernel mode vs the fp32 CPU oracle at the north_star tolerance (1e-4 relative), and
+    the bf16 production mode's error on the same pairs."""
+    from oracle import cpu_ref as R
+    cfg = C.SD15
+    keys = [k for k in C.unet_param_shapes(cfg) if not k.startswith(("up_blocks.2", "up_blocks.3", "conv_norm_out", "conv_out"))]
+    sd = S.make_state_dict(cfg, seed=0, keys=keys)
+    full = dict(sd)
+    for k, shp in C.unet_param_shapes(cfg).items():
+        if k not in full:
+            full[k] = torch.zeros(shp)
+    unet = R.build_unet(R.SD15, full)
+    del full
+    ctx = S.make_context(cfg)
+    n = S.draw_pair_noise(2334, (1, 4, 64, 64))
+    lats = [S.make_pair_latents(cfg, i) for i in range(2)]
+    want = [float(R.diffsim_latents(unet, a, b, n[2], n[3], ctx)) for a, b in lats]
+    zA = torch.cat([p[0] for p in lats]); zB = torch.cat([p[1] for p in lats])
+    got32 = _scorer(cfg, sd, torch.float32).score_latent_pairs(zA, zB, n[2], n[3], ctx).cpu()
+    for s, w in zip(got32.tolist(), want):
+        assert _rel(s, w) <= REL_F32, (s, w)
+    got16 = _scorer(cfg, sd, torch.bfloat16).score_latent_pairs(zA, zB, n[2], n[3], ctx).cpu()
+    for s, w in zip(got16.tolist(), want):
+        assert abs(s - w) <= 5e-3, (s, w)

@@ -50,7 +50,6 @@ template <typename T, int D> struct ACfg {
     static constexpr int TILEK = KT * RS;
     static constexpr int TILE = (KT * RS + KT * RSV + 1) / 2;   // average, so that 2*TILE = K tile + V tile
     static constexpr bool PIPE = sizeof(T) == 2;
-    static constexpr int NSR = (KT * CPR + 255) / 256;     // 16-B chunks of K (and of V) per thread per tile
     static constexpr int LDS = (PIPE ? 4 : 2) * TILE;
     // waves per SIMD the register budget is held to (occupancy hides the serial MFMA/VALU phases)
     static constexpr int WPS = (sizeof(T) == 2 && DPL <= 64) ? 3 : ((sizeof(T) == 2 && DPL <= 96) ? 2 : 1);
@@ -107,47 +106,73 @@ __device__ __forceinline__ void load_q(QFrags<T, D>& qf, const T* qrow /*row bas
     }
 }
 
-// Staging of one KT-row tile of K and V, split in a load half and a store half so the global loads
-// can be issued a whole tile ahead of the LDS writes.  Rows >= Nk and columns >= D are zero; with
-// ONES the V tile gets 1.0 in column D of every valid row.
-template <typename T, int D> struct StageRegs { u32x4 k[ACfg<T, D>::NSR], v[ACfg<T, D>::NSR]; };
+// Staging of one KT-row tile of K and V, split in a load half and a store half so the global loads can be
+// issued a whole tile ahead of the LDS writes.  Only the D real columns move per tile: the zero padding up
+// to DPL columns (and, with ONES, the 1.0 in column D of V) is written ONCE per attend() by tile_init.
+// Rows >= Nk of a ragged tile are never stored: they keep zeros or stale finite values, and their scores
+// are masked to -inf, so they contribute exactly 0.
+template <typename T, int D> struct StageRegs {
+    static constexpr int CPRD = D / ACfg<T, D>::VEC;                 // real 16-B chunks per row
+    static constexpr int N = (KT * CPRD + 255) / 256;
+    u32x4 k[N], v[N];
+    unsigned goff[N];       // element offset of this thread's chunk inside a tile (row * ldk + col)
+    unsigned loff[N];       // byte offset inside the K tile image; the V image uses lvoff
+    unsigned lvoff[N];
+    int row[N];             // tile row, or KT when this thread has no chunk in round i
+};
 
 template <typename T> __device__ __forceinline__ u32x4 one_chunk();
 template <> __device__ __forceinline__ u32x4 one_chunk<bf16>() { u32x4 r = {0x00003F80u, 0u, 0u, 0u}; return r; }   // bf16 1.0 in element 0
 template <> __device__ __forceinline__ u32x4 one_chunk<float>() { u32x4 r = {0x3F800000u, 0u, 0u, 0u}; return r; }
 
 template <typename T, int D>
-__device__ __forceinline__ void tile_load(StageRegs<T, D>& sr, const T* kb, const T* vb, int ldk, int kv0, int Nk, int tid) {
+__device__ __forceinline__ void tile_init(StageRegs<T, D>& sr, char* lds, int ldk, int Nk, int tid) {
     typedef ACfg<T, D> C;
+    typedef StageRegs<T, D> SR;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    // zero fill is needed for the padding columns and for the never-stored rows of a ragged last tile
+    if (D < C::DPL || (Nk % KT) != 0)
+        for (int o = tid * 16; o < C::LDS; o += 256 * 16) *reinterpret_cast<u32x4*>(lds + o) = z;
 #pragma unroll
-    for (int i = 0; i < C::NSR; ++i) {
+    for (int i = 0; i < SR::N; ++i) {
         const int idx = tid + i * 256;
-        const int r = idx / C::CPR, c = idx - r * C::CPR;
-        const int kv = kv0 + r;
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        sr.k[i] = z;
-        sr.v[i] = z;
-        if (idx < KT * C::CPR && kv < Nk) {
-            if (c * C::VEC < D) {
-                const size_t off = (size_t)kv * ldk + c * C::VEC;
-                sr.k[i] = *reinterpret_cast<const u32x4*>(kb + off);
-                sr.v[i] = *reinterpret_cast<const u32x4*>(vb + off);
-            } else if (C::ONES && c * C::VEC == D) {
-                sr.v[i] = one_chunk<T>();
-            }
+        const int r = idx / SR::CPRD, c = idx - r * SR::CPRD;
+        sr.row[i] = idx < KT * SR::CPRD ? r : KT;
+        sr.goff[i] = (unsigned)r * (unsigned)ldk + (unsigned)c * C::VEC;
+        sr.loff[i] = (unsigned)(r * C::RS + c * 16);
+        sr.lvoff[i] = (unsigned)(C::TILEK + r * C::RSV + c * 16);
+    }
+    if constexpr (C::ONES) {
+        __syncthreads();
+        constexpr int NBUF = C::PIPE ? 2 : 1;
+        for (int i = tid; i < KT * NBUF; i += 256) {
+            const int buf = i / KT, r = i - buf * KT;
+            *reinterpret_cast<u32x4*>(lds + buf * 2 * C::TILE + C::TILEK + r * C::RSV + (D / C::VEC) * 16) = one_chunk<T>();
+        }
+    }
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void tile_load(StageRegs<T, D>& sr, const T* kb, const T* vb, int ldk, int kv0, int Nk) {
+    typedef StageRegs<T, D> SR;
+    const T* kt = kb + (size_t)kv0 * ldk;
+    const T* vt = vb + (size_t)kv0 * ldk;
+#pragma unroll
+    for (int i = 0; i < SR::N; ++i) {
+        if (kv0 + sr.row[i] < Nk && sr.row[i] < KT) {
+            sr.k[i] = *reinterpret_cast<const u32x4*>(kt + sr.goff[i]);
+            sr.v[i] = *reinterpret_cast<const u32x4*>(vt + sr.goff[i]);
         }
     }
 }
 template <typename T, int D>
-__device__ __forceinline__ void tile_store(char* lds, const StageRegs<T, D>& sr, int tid) {
-    typedef ACfg<T, D> C;
+__device__ __forceinline__ void tile_store(char* lds, const StageRegs<T, D>& sr, int kv0, int Nk) {
+    typedef StageRegs<T, D> SR;
 #pragma unroll
-    for (int i = 0; i < C::NSR; ++i) {
-        const int idx = tid + i * 256;
-        const int r = idx / C::CPR, c = idx - r * C::CPR;
-        if (idx < KT * C::CPR) {
-            *reinterpret_cast<u32x4*>(lds + r * C::RS + c * 16) = sr.k[i];
-            *reinterpret_cast<u32x4*>(lds + C::TILEK + r * C::RSV + c * 16) = sr.v[i];
+    for (int i = 0; i < SR::N; ++i) {
+        if (kv0 + sr.row[i] < Nk && sr.row[i] < KT) {
+            *reinterpret_cast<u32x4*>(lds + sr.loff[i]) = sr.k[i];
+            *reinterpret_cast<u32x4*>(lds + sr.lvoff[i]) = sr.v[i];
         }
     }
 }
@@ -172,22 +197,22 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
 
     const int ntiles = (Nk + KT - 1) / KT;
     StageRegs<T, D> sr;
-    if constexpr (C::PIPE) {
-        tile_load<T, D>(sr, kb, vb, ldk, 0, Nk, tid);
-        __syncthreads();        // a previous attend() of this workgroup may still be reading the buffers
-    }
+    __syncthreads();            // a previous attend() of this workgroup may still be reading the buffers
+    tile_init<T, D>(sr, lds, ldk, Nk, tid);
+    if constexpr (C::PIPE) tile_load<T, D>(sr, kb, vb, ldk, 0, Nk);
+    __syncthreads();
     char* const lds0 = lds;
     for (int kt = 0; kt < ntiles; ++kt) {
         if constexpr (C::PIPE) {
             // buffer (kt&1) was last read in iteration kt-2; every wave has passed barrier kt-1 since
             lds = lds0 + (kt & 1) * 2 * C::TILE;
-            tile_store<T, D>(lds, sr, tid);
+            tile_store<T, D>(lds, sr, kt * KT, Nk);
             __syncthreads();
-            if (kt + 1 < ntiles) tile_load<T, D>(sr, kb, vb, ldk, (kt + 1) * KT, Nk, tid);
+            if (kt + 1 < ntiles) tile_load<T, D>(sr, kb, vb, ldk, (kt + 1) * KT, Nk);
         } else {
             __syncthreads();                               // previous tile fully consumed
-            tile_load<T, D>(sr, kb, vb, ldk, kt * KT, Nk, tid);
-            tile_store<T, D>(lds, sr, tid);
+            tile_load<T, D>(sr, kb, vb, ldk, kt * KT, Nk);
+            tile_store<T, D>(lds, sr, kt * KT, Nk);
             __syncthreads();
         }
 

@@ -62,6 +62,55 @@ def pmc_traffic(kernel: str):
     return None
 
 
+def secondary(a, world, rank, dev):
+    """Secondary bench lines: DiffSim-XL (SDXL U-Net, 1024 px, tap up_blocks [0,0,0]) and DiffSim-DiT (DiT-XL/2,
+    256 px, tap blocks[13]) -- same step definition (latents resident in HBM -> scores), synthetic weights."""
+    from diffsim_amd.engine import pair_score
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    bp = a.batch_pairs
+    if a.model == "sdxl":
+        from diffsim_amd.diffsim_xl import diffsim_xl
+        cfg = C.SDXL
+        drop = ("up_blocks.1", "up_blocks.2", "conv_norm_out", "conv_out", "up_blocks.0.attentions.1", "up_blocks.0.attentions.2",
+                "up_blocks.0.resnets.1", "up_blocks.0.resnets.2", "up_blocks.0.upsamplers")
+        keys = [k for k in C.unet_param_shapes(cfg) if not k.startswith(drop)]
+        sc = diffsim_xl(dtype, str(dev), unet_config=cfg, state_dict=S.make_state_dict(cfg, seed=0, keys=keys))
+        ctx, pooled = S.make_context(cfg), S.make_pooled(cfg)
+        shp = (1, 4, cfg.sample_size, cfg.sample_size)
+        g = torch.Generator("cpu").manual_seed(1234 + rank)
+        zA, zB = torch.randn((bp,) + shp[1:], generator=g), torch.randn((bp,) + shp[1:], generator=g)
+        n = S.draw_pair_noise(2334, shp)
+        run = lambda: sc.score_latent_pairs(zA, zB, n[2], n[3], ctx, pooled, "up_blocks", [0, 0, 0], 600, "cosine", batch_pairs=bp)
+        name = "DiffSim-XL (SDXL U-Net), synthetic 1024px pairs (latents-in), up_blocks [0,0,0] step 600, cosine"
+    else:
+        from diffsim_amd.diffsim_dit import diffsim_DiT
+        cfg = C.DIT_XL2
+        keys = [k for k in C.dit_param_shapes(cfg) if not (k.startswith("blocks.") and int(k.split(".")[1]) > 13)]
+        sc = diffsim_DiT(256, 600, str(dev), dit_config=cfg, state_dict=S.make_state_dict(cfg, seed=0, keys=keys), torch_dtype=dtype)
+        shp = (1, 4, 32, 32)
+        g = torch.Generator("cpu").manual_seed(1234 + rank)
+        zA, zB = torch.randn((bp,) + shp[1:], generator=g), torch.randn((bp,) + shp[1:], generator=g)
+        n = S.draw_pair_noise(2334, shp)
+        run = lambda: sc.score_latent_pairs(zA, zB, n[2], n[3], 13, 600, "cosine", batch_pairs=bp)
+        name = "DiffSim-DiT (DiT-XL/2), synthetic 256px pairs (latents-in), blocks[13] step 600, cosine"
+    zA, zB = zA.to(dev), zB.to(dev)
+    n = [t.to(dev) for t in n]
+    for _ in range(a.warmup):
+        scores = run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        scores = run()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": "image-pairs/sec (secondary config)", "value": round(world * a.steps * bp / el, 3), "unit": "pairs/s",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * el / a.steps, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                          "config": {"workload": name, "pairs_per_step_per_gpu": bp},
+                          "score_sample": [round(float(x), 6) for x in scores[:4].float().cpu()]}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +120,8 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--model", choices=["sd15", "sdxl", "dit"], default="sd15",
+                    help="sd15 = the headline metric (BASELINE config[1]); sdxl / dit = secondary lines for configs[3], [4]")
     ap.add_argument("--pixels-in", action="store_true",
                     help="secondary line: include the VAE encoder (512x512 pixels in HBM -> score); the headline "
                          "metric is latents-in")
@@ -91,6 +142,8 @@ def main():
     from diffsim_amd.diffsim import DiffSim
     from diffsim_amd.engine import pair_score
 
+    if a.model != "sd15":
+        return secondary(a, world, rank, dev)
     cfg = C.SD15
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     keys = [k for k in C.unet_param_shapes(cfg) if not k.startswith(TAP_KEYS_EXCLUDE)]

@@ -20,6 +20,11 @@ namespace {
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAX_SLOTS = 4;     // channel slots (16 B each) a thread may own: C <= 4*256*VEC
 
+// x*sigmoid(x) with the hardware exp2/rcp (1 ulp each): the apply pass is otherwise VALU-bound on libm's expf + divide
+__device__ __forceinline__ float silu_fast(float y) {
+    return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y));
+}
+
 template <typename T> struct Vec16;
 template <> struct Vec16<bf16> { typedef bf16x8 type; static constexpr int N = 8; };
 template <> struct Vec16<float> { typedef f32x4 type; static constexpr int N = 4; };
@@ -37,8 +42,8 @@ __device__ __forceinline__ typename Vec16<T>::type load_slot(const T* x0, int C0
                    : *reinterpret_cast<const V*>(x1 + row * C1 + (ch - C0));
 }
 
-// grid (chunks, B)
-template <typename T>
+// grid (chunks, B); NS = channel slots per thread, UNR = rows in flight per thread
+template <typename T, int NS, int UNR>
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restrict__ x0, int C0,
                                                               const T* __restrict__ x1, int C1, int HW,
                                                               int groups, double* __restrict__ part) {
@@ -52,17 +57,44 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
     const int chunks = gridDim.x, chunk = blockIdx.x, b = blockIdx.y;
     const int r0 = (int)((long)HW * chunk / chunks), r1 = (int)((long)HW * (chunk + 1) / chunks);
 
-    float s1[GN_MAX_SLOTS][VEC], s2[GN_MAX_SLOTS][VEC];
+    float s1[NS][VEC], s2[NS][VEC];
 #pragma unroll
-    for (int k = 0; k < GN_MAX_SLOTS; ++k)
+    for (int k = 0; k < NS; ++k)
 #pragma unroll
         for (int e = 0; e < VEC; ++e) s1[k][e] = s2[k][e] = 0.f;
 
     if (trow < R) {
-        for (int r = r0 + trow; r < r1; r += R) {
+        // UNR rows in flight per thread: all loads of a batch are issued before the first is consumed
+        typedef typename Vec16<T>::type V;
+        int r = r0 + trow;
+        for (; r + (UNR - 1) * R < r1; r += UNR * R) {
+            V v[UNR][NS];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const int slot = tcol + k * tpr;
+                    if (slot < S) v[u][k] = load_slot<T>(x0, C0, x1, C1, (size_t)b * HW + r + u * R, slot * VEC);
+                }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const int slot = tcol + k * tpr;
+                    if (slot < S) {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const float f = (float)v[u][k][e];
+                            s1[k][e] += f;
+                            s2[k][e] = fmaf(f, f, s2[k][e]);
+                        }
+                    }
+                }
+        }
+        for (; r < r1; r += R) {
             const size_t row = (size_t)b * HW + r;
 #pragma unroll
-            for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+            for (int k = 0; k < NS; ++k) {
                 const int slot = tcol + k * tpr;
                 if (slot < S) {
                     auto v = load_slot<T>(x0, C0, x1, C1, row, slot * VEC);
@@ -80,7 +112,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
     float* lds = reinterpret_cast<float*>(smem);
     if (trow < R) {
 #pragma unroll
-        for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+        for (int k = 0; k < NS; ++k) {
             const int slot = tcol + k * tpr;
             if (slot < S) {
 #pragma unroll
@@ -108,7 +140,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
 }
 
 // grid (row_blocks, B)
-template <typename T, bool SILU>
+template <typename T, bool SILU, int NS, int UNR>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restrict__ x0, int C0,
                                                               const T* __restrict__ x1, int C1,
                                                               const float* __restrict__ gamma,
@@ -142,9 +174,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
     }
     __syncthreads();
     if (trow >= R) return;
-    float sc[GN_MAX_SLOTS][VEC], sh[GN_MAX_SLOTS][VEC];
+    float sc[NS][VEC], sh[NS][VEC];
 #pragma unroll
-    for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+    for (int k = 0; k < NS; ++k) {
         const int slot = tcol + k * tpr;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -161,10 +193,37 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
     const int rows_per_block = (HW + gridDim.x - 1) / gridDim.x;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = (r0 + rows_per_block < HW) ? r0 + rows_per_block : HW;
-    for (int r = r0 + trow; r < r1; r += R) {
+    int r = r0 + trow;
+    for (; r + (UNR - 1) * R < r1; r += UNR * R) {
+        V v[UNR][NS];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int slot = tcol + k * tpr;
+                if (slot < S) v[u][k] = load_slot<T>(x0, C0, x1, C1, (size_t)b * HW + r + u * R, slot * VEC);
+            }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int slot = tcol + k * tpr;
+                if (slot < S) {
+                    V o;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        float y = fmaf((float)v[u][k][e], sc[k][e], sh[k][e]);
+                        if (SILU) y = silu_fast(y);
+                        o[e] = (T)y;
+                    }
+                    *reinterpret_cast<V*>(out + ((size_t)b * HW + r + u * R) * C + slot * VEC) = o;
+                }
+            }
+    }
+    for (; r < r1; r += R) {
         const size_t row = (size_t)b * HW + r;
 #pragma unroll
-        for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+        for (int k = 0; k < NS; ++k) {
             const int slot = tcol + k * tpr;
             if (slot < S) {
                 V v = load_slot<T>(x0, C0, x1, C1, row, slot * VEC);
@@ -172,7 +231,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     float y = fmaf((float)v[e], sc[k][e], sh[k][e]);
-                    if (SILU) y = y / (1.0f + expf(-y));
+                    if (SILU) y = silu_fast(y);
                     o[e] = (T)y;
                 }
                 *reinterpret_cast<V*>(out + row * C + slot * VEC) = o;
@@ -181,70 +240,103 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
     }
 }
 
-// one wave per row; 4 rows per workgroup
+// one wave per RPW consecutive rows (all RPW*MAXS loads of a wave are issued before any reduction, so narrow rows
+// -- C = 320 fills only 40 of 64 lanes -- still keep enough bytes in flight); 4 waves per workgroup.
 // MOD: no affine; y = xhat * (1 + scale[half][c]) + shift[half][c] with gamma = scale, beta = shift, [2][C] each
-template <typename T, bool MOD = false>
+template <typename T, bool MOD, int MAXS, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ out,
-                                                        int M, int C, float eps, int rows_per_batch = 1) {
-    constexpr int VEC = Vec16<T>::N;
-    constexpr int MAXS = 6;                 // C <= 64*6*VEC (3072 bf16 / 1536 f32)
+                                                        int M, int C, float eps, int rows_per_batch) {
+    constexpr int VEC = Vec16<T>::N;        // C <= 64*MAXS*VEC
     typedef typename Vec16<T>::type V;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= M) return;
     const int S = C / VEC;
-    const T* xr = x + (size_t)row * C;
-    float v[MAXS][VEC];
-    float sum = 0.f;
+    V t[RPW][MAXS];
 #pragma unroll
-    for (int k = 0; k < MAXS; ++k) {
-        const int slot = lane + k * 64;
-        if (slot < S) {
-            V t = *reinterpret_cast<const V*>(xr + slot * VEC);
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int row = row0 + rr < M ? row0 + rr : M - 1;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) { v[k][e] = (float)t[e]; sum += v[k][e]; }
-        } else {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) v[k][e] = 0.f;
+        for (int k = 0; k < MAXS; ++k) {
+            const int slot = lane + k * 64;
+            if (slot < S) t[rr][k] = *reinterpret_cast<const V*>(x + (size_t)row * C + slot * VEC);
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    const float mean = sum / (float)C;
-    float sq = 0.f;
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int row = row0 + rr;
+        if (row >= M) break;
+        float v[MAXS][VEC];
+        float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXS; ++k) {
-        const int slot = lane + k * 64;
-        if (slot < S) {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) { const float d = v[k][e] - mean; sq = fmaf(d, d, sq); }
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-    const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
-    T* orow = out + (size_t)row * C;
-#pragma unroll
-    for (int k = 0; k < MAXS; ++k) {
-        const int slot = lane + k * 64;
-        if (slot < S) {
-            V o;
+        for (int k = 0; k < MAXS; ++k) {
+            const int slot = lane + k * 64;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                const int c = slot * VEC + e;
-                if (MOD) {
-                    const int hoff = ((row / rows_per_batch) & 1) * C;
-                    o[e] = (T)fmaf((v[k][e] - mean) * rstd, 1.0f + gamma[hoff + c], beta[hoff + c]);
-                } else {
-                    o[e] = (T)fmaf((v[k][e] - mean) * rstd, gamma[c], beta[c]);
-                }
+                v[k][e] = slot < S ? (float)t[rr][k][e] : 0.f;
+                sum += v[k][e];
             }
-            *reinterpret_cast<V*>(orow + slot * VEC) = o;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXS; ++k) {
+            const int slot = lane + k * 64;
+            if (slot < S) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { const float d = v[k][e] - mean; sq = fmaf(d, d, sq); }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+        T* orow = out + (size_t)row * C;
+#pragma unroll
+        for (int k = 0; k < MAXS; ++k) {
+            const int slot = lane + k * 64;
+            if (slot < S) {
+                V o;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const int c = slot * VEC + e;
+                    if (MOD) {
+                        const int hoff = ((row / rows_per_batch) & 1) * C;
+                        o[e] = (T)fmaf((v[k][e] - mean) * rstd, 1.0f + gamma[hoff + c], beta[hoff + c]);
+                    } else {
+                        o[e] = (T)fmaf((v[k][e] - mean) * rstd, gamma[c], beta[c]);
+                    }
+                }
+                *reinterpret_cast<V*>(orow + slot * VEC) = o;
+            }
         }
     }
 }
 
+template <typename T, bool MOD>
+int ln_typed(const void* x, const float* gamma, const float* beta, void* out, int M, int C, float eps, int rpb,
+             hipStream_t s) {
+    constexpr int VEC = Vec16<T>::N;
+    if (C % VEC || C > 64 * 6 * VEC || M < 1) return DSIM_ERR_INVALID;
+    const int S = C / VEC;
+    const dim3 block(256);
+    if (S <= 64)
+        hipLaunchKernelGGL((layernorm_kernel<T, MOD, 1, 4>), dim3((M + 15) / 16), block, 0, s, (const T*)x, gamma, beta,
+                           (T*)out, M, C, eps, rpb);
+    else if (S <= 128)
+        hipLaunchKernelGGL((layernorm_kernel<T, MOD, 2, 2>), dim3((M + 7) / 8), block, 0, s, (const T*)x, gamma, beta,
+                           (T*)out, M, C, eps, rpb);
+    else if (S <= 192)
+        hipLaunchKernelGGL((layernorm_kernel<T, MOD, 3, 2>), dim3((M + 7) / 8), block, 0, s, (const T*)x, gamma, beta,
+                           (T*)out, M, C, eps, rpb);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<T, MOD, 6, 1>), dim3((M + 3) / 4), block, 0, s, (const T*)x, gamma, beta,
+                           (T*)out, M, C, eps, rpb);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
 
 // softmax over rows of `cols` elements (one 256-thread workgroup per row; cols % VEC == 0).  Used by
 // the VAE encoder's single-head 512-d mid-block attention, whose score matrix is materialised by
@@ -291,6 +383,21 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__
     }
 }
 
+template <typename T, int NS, int UNR>
+int gn_launch(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta, void* out, int B,
+              int HW, int groups, float eps, int silu, void* scratch, int chunks, int rb, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((gn_stats_kernel<T, NS, UNR>), dim3(chunks, B), dim3(GN_THREADS), lds, s, (const T*)x0, C0,
+                       (const T*)x1, C1, HW, groups, (double*)scratch);
+    if (silu)
+        hipLaunchKernelGGL((gn_apply_kernel<T, true, NS, UNR>), dim3(rb, B), dim3(GN_THREADS), 0, s, (const T*)x0, C0,
+                           (const T*)x1, C1, gamma, beta, (T*)out, HW, groups, eps, chunks, (const double*)scratch);
+    else
+        hipLaunchKernelGGL((gn_apply_kernel<T, false, NS, UNR>), dim3(rb, B), dim3(GN_THREADS), 0, s, (const T*)x0, C0,
+                           (const T*)x1, C1, gamma, beta, (T*)out, HW, groups, eps, chunks, (const double*)scratch);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+
 template <typename T>
 int gn_typed(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta,
              void* out, int B, int HW, int groups, float eps, int silu, void* scratch, hipStream_t s) {
@@ -303,20 +410,15 @@ int gn_typed(const void* x0, int C0, const void* x1, int C1, const float* gamma,
     const int chunks = gn_chunks(HW);
     const size_t lds = (size_t)R * C * 2 * sizeof(float);
     if (lds > 64 * 1024) return DSIM_ERR_INVALID;
-    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(chunks, B), dim3(GN_THREADS), lds, s, (const T*)x0, C0,
-                       (const T*)x1, C1, HW, groups, (double*)scratch);
     int rb = HW / (R * 4);
     rb = rb < 1 ? 1 : (rb > 64 ? 64 : rb);
-    if (silu)
-        hipLaunchKernelGGL((gn_apply_kernel<T, true>), dim3(rb, B), dim3(GN_THREADS), 0, s, (const T*)x0, C0,
-                           (const T*)x1, C1, gamma, beta, (T*)out, HW, groups, eps, chunks,
-                           (const double*)scratch);
-    else
-        hipLaunchKernelGGL((gn_apply_kernel<T, false>), dim3(rb, B), dim3(GN_THREADS), 0, s, (const T*)x0, C0,
-                           (const T*)x1, C1, gamma, beta, (T*)out, HW, groups, eps, chunks,
-                           (const double*)scratch);
-    DSIM_HIP_CHECK(hipGetLastError());
-    return DSIM_OK;
+    const int ns = (S + tpr - 1) / tpr;
+    if (ns == 1)
+        return gn_launch<T, 1, 4>(x0, C0, x1, C1, gamma, beta, out, B, HW, groups, eps, silu, scratch, chunks, rb, lds, s);
+    if (ns == 2)
+        return gn_launch<T, 2, 2>(x0, C0, x1, C1, gamma, beta, out, B, HW, groups, eps, silu, scratch, chunks, rb, lds, s);
+    return gn_launch<T, GN_MAX_SLOTS, 1>(x0, C0, x1, C1, gamma, beta, out, B, HW, groups, eps, silu, scratch, chunks, rb,
+                                         lds, s);
 }
 
 }  // namespace
@@ -335,32 +437,17 @@ int launch_groupnorm(const void* x0, int C0, const void* x1, int C1, const float
 
 int launch_layernorm(const void* x, const float* gamma, const float* beta, void* out, int M, int C, float eps,
                      int dtype, hipStream_t s) {
-    const int vec = dtype == DSIM_F32 ? 4 : 8;
-    if (C % vec || C > 64 * 6 * vec) return DSIM_ERR_INVALID;
-    const dim3 grid((M + 3) / 4), block(256);
-    if (dtype == DSIM_BF16)
-        hipLaunchKernelGGL((layernorm_kernel<bf16, false>), grid, block, 0, s, (const bf16*)x, gamma, beta, (bf16*)out, M, C, eps, 1);
-    else if (dtype == DSIM_F32)
-        hipLaunchKernelGGL((layernorm_kernel<float, false>), grid, block, 0, s, (const float*)x, gamma, beta, (float*)out, M, C, eps, 1);
-    else
-        return DSIM_ERR_INVALID;
-    DSIM_HIP_CHECK(hipGetLastError());
-    return DSIM_OK;
+    if (dtype == DSIM_BF16) return ln_typed<bf16, false>(x, gamma, beta, out, M, C, eps, 1, s);
+    if (dtype == DSIM_F32) return ln_typed<float, false>(x, gamma, beta, out, M, C, eps, 1, s);
+    return DSIM_ERR_INVALID;
 }
 
 int launch_layernorm_mod(const void* x, const float* scale2, const float* shift2, void* out, int M, int C,
                          int rows_per_batch, float eps, int dtype, hipStream_t s) {
-    const int vec = dtype == DSIM_F32 ? 4 : 8;
-    if (C % vec || C > 64 * 6 * vec || rows_per_batch < 1) return DSIM_ERR_INVALID;
-    const dim3 grid((M + 3) / 4), block(256);
-    if (dtype == DSIM_BF16)
-        hipLaunchKernelGGL((layernorm_kernel<bf16, true>), grid, block, 0, s, (const bf16*)x, scale2, shift2, (bf16*)out, M, C, eps, rows_per_batch);
-    else if (dtype == DSIM_F32)
-        hipLaunchKernelGGL((layernorm_kernel<float, true>), grid, block, 0, s, (const float*)x, scale2, shift2, (float*)out, M, C, eps, rows_per_batch);
-    else
-        return DSIM_ERR_INVALID;
-    DSIM_HIP_CHECK(hipGetLastError());
-    return DSIM_OK;
+    if (rows_per_batch < 1) return DSIM_ERR_INVALID;
+    if (dtype == DSIM_BF16) return ln_typed<bf16, true>(x, scale2, shift2, out, M, C, eps, rows_per_batch, s);
+    if (dtype == DSIM_F32) return ln_typed<float, true>(x, scale2, shift2, out, M, C, eps, rows_per_batch, s);
+    return DSIM_ERR_INVALID;
 }
 
 int launch_softmax_rows(const void* x, void* out, int rows, int cols, float scale, int dtype, hipStream_t s) {

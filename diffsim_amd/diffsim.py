@@ -53,7 +53,7 @@ class DiffSim:
     def __init__(self, torch_dtype=torch.bfloat16, device="cuda", ip_adapter=False, *,
                  unet_config: UNetConfig = SD15, state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  vae=None, encode_prompt: Optional[Callable[[str], torch.Tensor]] = None,
-                 vae_dtype=torch.float16):
+                 vae_dtype=torch.float16, use_graphs: bool = False):
         if ip_adapter:
             raise NotImplementedError("IP-Adapter mode is out of scope (SURVEY.md section 2 row 3)")
         if state_dict is None:
@@ -68,6 +68,7 @@ class DiffSim:
         self.vae = vae
         self.vae_dtype = vae_dtype
         self._encode_prompt = encode_prompt
+        self.use_graphs = use_graphs            # replay each U-Net forward as one hipGraph (small, launch-bound batches)
         self._engines: Dict[Tuple[str, int], UNetEngine] = {}
         self._ctx: Dict[str, torch.Tensor] = {}
 
@@ -77,6 +78,7 @@ class DiffSim:
         if key not in self._engines:
             self._engines[key] = UNetEngine(self.cfg, self.state_dict, self.dtype, target_block, target_layer,
                                             str(self.device))
+            self._engines[key].use_graphs = self.use_graphs
         return self._engines[key]
 
     def context(self, prompt: Union[str, torch.Tensor]) -> torch.Tensor:

@@ -119,6 +119,22 @@ def test_batch_invariance_and_determinism(tiny_env):
         assert float(s_all.min()) >= -1.0 and float(s_all.max()) <= 1.0
 
 
+def test_hipgraph_replay_is_bit_identical(tiny_env):
+    """use_graphs=True replays the captured forward; scores must equal the eager launches bit for bit, also after
+    new inputs are copied into the static buffers and after a timestep change invalidates the graphs."""
+    ctx = tiny_env["ctx"]
+    eager = _scorer(C.TINY, tiny_env["sd"], torch.bfloat16)
+    graph = _scorer(C.TINY, tiny_env["sd"], torch.bfloat16, use_graphs=True)
+    n = S.draw_pair_noise(2334, (1, 4, C.TINY.sample_size, C.TINY.sample_size))
+    for step in (600, 600, 750):
+        for i in range(3):
+            zA, zB = S.make_pair_latents(C.TINY, i)
+            a = eager.score_latent_pairs(zA, zB, n[2], n[3], ctx, "up_blocks", 0, step)
+            b = graph.score_latent_pairs(zA, zB, n[2], n[3], ctx, "up_blocks", 0, step)
+            assert torch.equal(a, b)
+    assert len(graph.engine("up_blocks", 0)._graphs) == 1
+
+
 def test_properties_slot_noise(tiny_env):
     ctx = tiny_env["ctx"]
     ds = _scorer(C.TINY, tiny_env["sd"], torch.float32)

@@ -53,6 +53,10 @@ template <> struct Traits<float> {
     static constexpr int VEC = 4;
 };
 
+template <typename T> struct Vec16T;
+template <> struct Vec16T<bf16> { typedef bf16x8 type; };
+template <> struct Vec16T<float> { typedef f32x4 type; };
+
 struct FragF32 { f32x4 lo, hi; };
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -319,9 +323,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     const int nout0 = GEGLU ? (nw0 >> 1) : nw0;
     const int Nout = GEGLU ? (p.N >> 1) : p.N;
     const int l31 = lane & 31;
+    typedef typename Vec16T<T>::type V16;
+    constexpr int NIT = (32 * CPR + 63) / 64;          // read-back iterations per 32-row slab
+    const bool has_res = p.epi == EPI_RESIDUAL;
+    const bool slow = p.act != 0 || p.gate != nullptr;  // DiT epilogues: activation / adaLN gate after the bias
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        // register phase
+        const int mrow0 = m0 + wm * (BM / WM) + i * 32;
+        // residual prefetch: every 16-byte piece this lane will add is requested before the slab is
+        // transposed, so the HBM latency hides under the register phase instead of serialising the stores
+        V16 rres[NIT];
+        if (has_res) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = lane + it * 64;
+                const int row = idx / CPR, c = idx - row * CPR;
+                const int m = mrow0 + row, ncol = c * VEC;
+                if (idx < 32 * CPR && m < p.M && nout0 + ncol < Nout)
+                    rres[it] = *reinterpret_cast<const V16*>(res + (size_t)m * p.ldo + nout0 + ncol);
+            }
+        }
+        // register phase: bias (f32, before the one rounding to T) and the D^T -> row-major transpose through LDS
+        const bool odd_half = p.bias2 && (((mrow0 + l31) / p.rows_per_batch) & 1);
 #pragma unroll
         for (int j = 0; j < TN; j += (GEGLU ? 2 : 1)) {
 #pragma unroll
@@ -339,8 +362,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                     for (int e = 0; e < 4; ++e)
                         v[e] = (acc[i][j][4 * g + e] + bh[e]) * gelu_erf(acc[i][j + 1][4 * g + e] + bg[e]);
                 } else {
+                    const int nb = nw0 + j * 32 + 8 * g + 4 * half;
+                    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias && nb < p.N) {
+                        b4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
+                        if (p.bias2) {
+                            const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.bias2 + nb);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                            for (int e = 0; e < 4; ++e) b4[e] = odd_half ? c4[e] : b4[e];
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + b4[e];
                 }
                 const int col = (GEGLU ? (j >> 1) : j) * 32 + 8 * g + 4 * half;
                 char* dst = wst + l31 * RSO + col * ES;
@@ -356,31 +389,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
             }
         }
         // read-back phase (same wave: LDS operations of one wave execute in order)
-        const int mrow0 = m0 + wm * (BM / WM) + i * 32;
-        for (int idx = lane; idx < 32 * CPR; idx += 64) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = lane + it * 64;
             const int row = idx / CPR, c = idx - row * CPR;
             const int m = mrow0 + row, ncol = c * VEC;
-            if (m < p.M && nout0 + ncol < Nout) {
+            if (idx < 32 * CPR && m < p.M && nout0 + ncol < Nout) {
                 const size_t o = (size_t)m * p.ldo + nout0 + ncol;
+                const V16 t = *reinterpret_cast<const V16*>(wst + row * RSO + c * 16);
+                if (!has_res && !slow) {                 // plain projection: LDS -> HBM copy
+                    *reinterpret_cast<V16*>(out + o) = t;
+                    continue;
+                }
                 float v[VEC];
-                if constexpr (sizeof(T) == 2) {
-                    const bf16x8 t8 = *reinterpret_cast<const bf16x8*>(wst + row * RSO + c * 16);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (float)t8[e];
-                } else {
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(wst + row * RSO + c * 16);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = t4[e];
-                }
-                if (!GEGLU && p.bias) {
-                    const float* bsel = (p.bias2 && ((m / p.rows_per_batch) & 1)) ? p.bias2 : p.bias;
-#pragma unroll
-                    for (int e = 0; e < VEC; e += 4) {
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bsel + nout0 + ncol + e);
-#pragma unroll
-                        for (int f = 0; f < 4; ++f) v[e + f] += b4[f];
-                    }
-                }
+                for (int e = 0; e < VEC; ++e) v[e] = (float)t[e];
                 if (p.act == 1) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {      // tanh-GELU: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
@@ -398,26 +421,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                         for (int f = 0; f < 4; ++f) v[e + f] *= g4[f];
                     }
                 }
-                if (p.epi == EPI_RESIDUAL) {
-                    if constexpr (sizeof(T) == 2) {
-                        const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(res + o);
+                if (has_res) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
-                    } else {
-                        const f32x4 r4 = *reinterpret_cast<const f32x4*>(res + o);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += r4[e];
-                    }
+                    for (int e = 0; e < VEC; ++e) v[e] += (float)rres[it][e];
                 }
-                if constexpr (sizeof(T) == 2) {
-                    bf16x8 o8;
+                V16 o16;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o8[e] = (bf16)v[e];
-                    *reinterpret_cast<bf16x8*>(out + o) = o8;
-                } else {
-                    f32x4 o4 = {v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(out + o) = o4;
-                }
+                for (int e = 0; e < VEC; ++e) o16[e] = (T)v[e];
+                *reinterpret_cast<V16*>(out + o) = o16;
             }
         }
     }

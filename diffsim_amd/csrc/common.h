@@ -57,9 +57,10 @@ struct GemmArgs {
     void* out = nullptr;
     int ldo = 0;
     const void* zero_page = nullptr;            // >= 16 zero bytes (kept for ABI stability; padding now comes from OOB buffer reads)
-    unsigned a0_bytes = 0, a1_bytes = 0, w_bytes = 0;   // filled by launch_gemm: operand extents for the buffer descriptors
+    unsigned a0_bytes = 0, a1_bytes = 0, w_bytes = 0, out_bytes = 0;   // filled by launch_gemm: operand extents for the buffer descriptors
 };
 int launch_gemm(const GemmArgs& a, int dtype, hipStream_t s);
+extern int g_gemm_persistent;
 extern int g_force_bm;     // 0 = heuristic; 128/256 force the row tile (micro-benchmark A/B only)
 void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn);   // which template instantiation launch_gemm picks
 

@@ -20,6 +20,7 @@ namespace dsim {
 // tile choice: 160-wide tiles when N allows (every SD channel count is a multiple of 160),
 // 256-row tiles once they still give >= one workgroup per CU.
 int g_force_bm = 0;
+int g_gemm_persistent = 1;   // development override (kbench A/B): 0 = one tile per workgroup
 // Tile choice.  Small problems: 128-row tiles, 4 waves, two workgroups per CU (160-wide when N
 // allows -- every SD channel count is a multiple of 160 -- else 128).  bf16 problems with enough
 // 256-row tiles to fill the chip: 256 x 320 (or 256 x 256) tiles, 8 waves as 4 x 2.
@@ -104,24 +105,35 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 
-// LDS: two staging buffers for the K loop; the epilogue's four wave-private transpose slabs reuse them
-template <typename T, int BM, int BN, bool GEGLU, int WM, int WN, int NST>
+// LDS: [stage buffer 0][spare][stage buffer 1].  The epilogue's wave-private transpose slabs live in the buffer the
+// last K step read plus the spare, so the OTHER buffer can already receive the next tile's first K stage while the
+// epilogue runs (persistent workgroups, see gemm_kernel).
+template <typename T, int BM, int BN, bool GEGLU, int WM, int WN>
+constexpr int gemm_epi_bytes() {
+    return WM * WN * 32 * ((GEGLU ? BN / WN / 2 : BN / WN) * (int)sizeof(T) + 16);
+}
+template <typename T, int BM, int BN, bool GEGLU, int WM, int WN>
+constexpr int gemm_spare_bytes() {
+    const int stage = (BM + BN) * 128, epi = gemm_epi_bytes<T, BM, BN, GEGLU, WM, WN>();
+    return epi > stage ? ((epi - stage + 1023) / 1024) * 1024 : 0;
+}
+template <typename T, int BM, int BN, bool GEGLU, int WM, int WN>
 constexpr int gemm_lds_bytes() {
-    const int stages = NST * (BM + BN) * 128;
-    const int epi = WM * WN * 32 * ((GEGLU ? BN / WN / 2 : BN / WN) * (int)sizeof(T) + 16);
-    return stages > epi ? stages : epi;
+    return 2 * (BM + BN) * 128 + gemm_spare_bytes<T, BM, BN, GEGLU, WM, WN>();
 }
 
 // WM x WN waves; each owns a (BM/WM) x (BN/WN) sub-tile, so an A fragment is reused by BN/WN/32 MFMAs and
 // a B fragment by BM/WM/32: with 64 x 160 per wave the LDS read traffic per MFMA is 0.7 fragments
 // against 1.2 for 32 x 160 (the 4x1 layout) -- the LDS port, not the MFMA pipe, was the limiter there.
-// NST LDS stages:
-//   NST == 2: stage t+1 is issued at the top of step t and drained (vmcnt(0)) at its end;
-//   NST == 3: stage t+2 is issued at the top of step t and only stage t+1 -- a counted vmcnt --
-//             must have landed before the step's barrier, so a whole K tile of loads stays in
-//             flight across every barrier (raw s_barrier: __syncthreads() would drain the DMA).
-template <typename T, int BM, int BN, int MODE, bool GEGLU, int WM, int WN, int NST>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p, const int tilesN) {
+// Persistent workgroups: the grid is one (or two) workgroups per CU; each walks tiles vb = blockIdx.x + i * gridDim.x
+// (XCD-aware order).  After a tile's K loop the next tile's first stage is issued into the free staging buffer
+// BEFORE the epilogue, so its HBM latency and the epilogue's stores overlap instead of serialising per tile.
+// EK (epilogue kind): EK_PLAIN bias only; EK_RES + residual; EK_SLOW the DiT epilogues (tanh-GELU activation, adaLN
+// gate, optional residual decided at run time).  Compile-time, because a run-time residual flag makes hipcc keep
+// every prefetched residual register in scratch, and the DiT math would add its register pressure to all users.
+enum { EK_PLAIN = 0, EK_RES = 1, EK_SLOW = 2 };
+template <typename T, int BM, int BN, int MODE, bool GEGLU, int WM, int WN, int EK>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p, const int tilesN, const int ntiles) {
     constexpr int NW = WM * WN;
     constexpr int BK = Traits<T>::BK;
     constexpr int KSUB = Traits<T>::KSUB;
@@ -132,19 +144,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     constexpr int NBP = BN / 8;                            // 8-row DMA pieces of B per stage (all waves)
     constexpr int NB = (NBP + NW - 1) / NW;                // ... per wave (the last one may be partial)
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int SPARE = gemm_spare_bytes<T, BM, BN, GEGLU, WM, WN>();
     typedef typename FragOf<T>::type Frag;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware bijective remap: the 8 XCDs take consecutive block ids round-robin; give each
-    // XCD a contiguous run of logical tiles so that tiles sharing an A panel share an L2.
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7, slot = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    }
-    const int m0 = (bid / tilesN) * BM, n0 = (bid % tilesN) * BN;
-
     const int lrow = lane >> 3;                                   // row inside an 8-row DMA piece
     const int wrow = wave * 8 + lrow;                             // row inside a 32-row group
     const unsigned celb = ((lane & 7) ^ ((wrow >> 1) & 7)) * 16;  // swizzled source chunk (bytes)
@@ -156,50 +160,58 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A0, 0, (int)p.a0_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A1 ? p.A1 : p.A0), 0, (int)p.a1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual ? p.residual : p.out), 0, (int)p.out_bytes, 0x00020000);
 
-    // ---- per-thread A row state ----------------------------------------------------------
+    // ---- per-thread state of the tile being staged ---------------------------------------------
+    int m0 = 0, n0 = 0;
     int a_iy0[NA], a_ix0[NA];
     unsigned a_base[NA], a_voff[NA];
-    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int m = m0 + i * (NW * 8) + wrow;
-        if (MODE == GEMM_CONV3) {
-            const int hw = p.Hout * p.Wout;
-            const int b = m / hw, rem = m - b * hw;
-            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-            a_iy0[i] = (m < p.M) ? oy * p.stride - p.pad : -(1 << 20);
-            a_ix0[i] = ox * p.stride - p.pad;
-            a_base[i] = (unsigned)b * (unsigned)(p.Hin * p.Win);
-            a_voff[i] = OOB;
-        } else {
-            a_iy0[i] = a_ix0[i] = 0;
-            a_base[i] = (m < p.M) ? (unsigned)m : OOB;
-            a_voff[i] = (m < p.M) ? (unsigned)m * (unsigned)p.C0 * (unsigned)sizeof(T) + celb : OOB;
-        }
-    }
     unsigned b_voff[NB];
+    const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
+    auto setup = [&](int vb) {
+        // XCD-aware bijective remap: the 8 XCDs take consecutive block ids round-robin (gridDim.x is a multiple
+        // of 8 whenever a workgroup walks more than one tile); give each XCD a contiguous run of logical tiles so
+        // that tiles sharing an A panel share an L2.
+        const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7, slot = vb >> 3;
+        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        m0 = (bid / tilesN) * BM;
+        n0 = (bid % tilesN) * BN;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int n = n0 + i * (NW * 8) + wrow;
-        b_voff[i] = (n < p.N) ? (unsigned)n * (unsigned)p.K * (unsigned)sizeof(T) + celb : OOB;
-    }
+        for (int i = 0; i < NA; ++i) {
+            const int m = m0 + i * (NW * 8) + wrow;
+            if (MODE == GEMM_CONV3) {
+                const int hw = p.Hout * p.Wout;
+                const int b = m / hw, rem = m - b * hw;
+                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                a_iy0[i] = (m < p.M) ? oy * p.stride - p.pad : -(1 << 20);
+                a_ix0[i] = ox * p.stride - p.pad;
+                a_base[i] = (unsigned)b * (unsigned)(p.Hin * p.Win);
+                a_voff[i] = OOB;
+            } else {
+                a_iy0[i] = a_ix0[i] = 0;
+                a_base[i] = (m < p.M) ? (unsigned)m : OOB;
+                a_voff[i] = (m < p.M) ? (unsigned)m * (unsigned)p.C0 * (unsigned)sizeof(T) + celb : OOB;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int n = n0 + i * (NW * 8) + wrow;
+            b_voff[i] = (n < p.N) ? (unsigned)n * (unsigned)p.K * (unsigned)sizeof(T) + celb : OOB;
+        }
+    };
     // B pieces this wave really issues per stage (wave-uniform): the tail piece exists only for
     // the first NBP % NW waves
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const bool b_tail = (NBP % NW == 0) || wave_u < (NBP % NW);
 
-    auto stage = [&](int t, int buf) {
-        char* sa = smem + buf * STAGE;
-        char* sb = sa + A_BYTES;
+    // K-tile t of the tile being staged: derive() refreshes the per-row offsets at a conv tap / second-source
+    // boundary, issue() launches the LDS-DMA pieces of this wave into staging buffer `buf`
+    auto derive = [&](int t) {
         const int k0 = t * BK;
-        int soff;
-        bool second = false;
         if (MODE == GEMM_CONV3) {
             const int tap = k0 / p.C0;
-            const int koff = k0 - tap * p.C0;
-            soff = koff * (int)sizeof(T);
-            if (koff == 0) {   // first K tile of a tap: re-derive the gathered pixel of every row
+            if (k0 == tap * p.C0) {   // first K tile of a tap: re-derive the gathered pixel of every row
                 const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
@@ -209,14 +221,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                     a_voff[i] = ok ? pix * (unsigned)p.C0 * (unsigned)sizeof(T) + celb : OOB;
                 }
             }
+        } else if (k0 == p.C0) {      // first K tile of the concatenated second source
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                a_voff[i] = a_base[i] != OOB ? a_base[i] * (unsigned)p.C1 * (unsigned)sizeof(T) + celb : OOB;
+        }
+    };
+    auto issue = [&](int t, int buf) {
+        char* sa = smem + (buf ? STAGE + SPARE : 0);
+        char* sb = sa + A_BYTES;
+        const int k0 = t * BK;
+        int soff;
+        bool second = false;
+        if (MODE == GEMM_CONV3) {
+            const int tap = k0 / p.C0;
+            soff = (k0 - tap * p.C0) * (int)sizeof(T);
         } else {
             second = k0 >= p.C0;
             soff = (second ? k0 - p.C0 : k0) * (int)sizeof(T);
-            if (second && k0 == p.C0) {   // first K tile of the concatenated second source
-#pragma unroll
-                for (int i = 0; i < NA; ++i)
-                    a_voff[i] = a_base[i] != OOB ? a_base[i] * (unsigned)p.C1 * (unsigned)sizeof(T) + celb : OOB;
-            }
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -231,15 +253,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(sb + (i * NW + wave) * 1024),
                                                          16, (int)b_voff[i], soffw, 0, 0);
     };
+    auto stage = [&](int t, int buf) { derive(t); issue(t, buf); };
 
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
     const int nk = p.K / BK;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int half = lane >> 5;
@@ -247,8 +263,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     const int frow = (lane & 31) * 128;
 
     auto compute = [&](int buf) {
-        const char* sa = smem + buf * STAGE + wm * (BM / WM) * 128 + frow;
-        const char* sb = smem + buf * STAGE + A_BYTES + wn * WBN * 128 + frow;
+        const char* sa = smem + (buf ? STAGE + SPARE : 0) + wm * (BM / WM) * 128 + frow;
+        const char* sb = smem + (buf ? STAGE + SPARE : 0) + A_BYTES + wn * WBN * 128 + frow;
         // fragments are register double-buffered: the ds_reads of step kk+1 are in flight while the
         // MFMAs of step kk run, so only the first read of a K tile exposes LDS latency
         Frag fa[2][TM], fb[2][TN];
@@ -275,136 +291,151 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
         }
     };
 
-    if constexpr (NST == 2) {
-        stage(0, 0);
+    constexpr int ES = sizeof(T);
+    constexpr int OUTW = GEGLU ? WBN / 2 : WBN;        // output columns this wave produces
+    constexpr int RSO = OUTW * ES + 16;                 // staging row stride (bytes)
+    constexpr int CPR = OUTW * ES / 16;                 // 16-byte chunks per output row
+    const int Nout = GEGLU ? (p.N >> 1) : p.N;
+    typedef typename Vec16T<T>::type V16;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NIT = (32 * CPR + 63) / 64;          // read-back iterations per 32-row slab
+    constexpr bool SLOW = EK == EK_SLOW;
+    const bool has_res = EK == EK_RES || (SLOW && p.epi == EPI_RESIDUAL);
+
+    int vb = blockIdx.x;
+    int b0 = 0;                                         // staging buffer holding K stage 0 of the current tile
+    setup(vb);
+    stage(0, 0);
+    while (true) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        // stage 0 has landed in every wave; every wave is past the previous tile's epilogue (its LDS slabs are free)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int t = 0; t < nk; ++t) {
-            const int cur = t & 1;
+            const int cur = b0 ^ (t & 1);
             if (t + 1 < nk) stage(t + 1, cur ^ 1);
             compute(cur);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-    } else {
-        // loads of one stage by this wave: NA + NB (or NB-1 without the tail piece)
-        stage(0, 0);
-        if (nk > 1) stage(1, 1);
-        int buf = 0;
-        for (int t = 0; t < nk; ++t) {
-            // stage t must have landed; the newer stage t+1 (if any) may stay in flight
-            if (t + 1 < nk) {
-                if (b_tail) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
-                else        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB - 1) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();       // every wave's share of stage t is in LDS; step t-1 fully consumed
-            if (t + 2 < nk) stage(t + 2, buf == 0 ? 2 : buf - 1);      // into the buffer step t-1 read
-            compute(buf);
-            buf = buf == 2 ? 0 : buf + 1;
+        const int xbuf = b0 ^ ((nk - 1) & 1);          // buffer the last K step read: epilogue scratch = it + spare
+        const int em0 = m0, en0 = n0;
+        const int nvb = vb + (int)gridDim.x;
+        const bool more = nvb < ntiles;
+        if (more) {                                     // next tile's first stage flies during the epilogue
+            setup(nvb);
+            stage(0, xbuf ^ 1);
         }
-        __builtin_amdgcn_s_barrier();           // all waves done with the last stage before the epilogue reuses LDS
-    }
-
     // ---- epilogue -------------------------------------------------------------------------
     // The accumulators hold D^T: lane = output row m (lane&31), registers = 16 output columns
     // n = 8*(r>>2) + 4*half + (r&3) of a 32-wide block.  Each wave transposes its 32-row slab
-    // through a private LDS region (the K loop's last barrier freed the staging buffers), then
+    // through a private LDS region (the K loop's last barrier freed the buffer it lives in), then
     // streams it out row-contiguously: 16-byte coalesced residual loads and stores.
-    constexpr int ES = sizeof(T);
-    constexpr int OUTW = GEGLU ? WBN / 2 : WBN;        // output columns this wave produces
-    constexpr int RSO = OUTW * ES + 16;                 // staging row stride (bytes)
-    constexpr int CPR = OUTW * ES / 16;                 // 16-byte chunks per output row
-    char* const wst = smem + wave * (32 * RSO);
-    T* const out = (T*)p.out;
-    const T* const res = (const T*)p.residual;
-    const int nw0 = n0 + wn * WBN;                     // first packed weight row of this wave
-    const int nout0 = GEGLU ? (nw0 >> 1) : nw0;
-    const int Nout = GEGLU ? (p.N >> 1) : p.N;
-    const int l31 = lane & 31;
-    typedef typename Vec16T<T>::type V16;
-    constexpr int NIT = (32 * CPR + 63) / 64;          // read-back iterations per 32-row slab
-    const bool has_res = p.epi == EPI_RESIDUAL;
-    const bool slow = p.act != 0 || p.gate != nullptr;  // DiT epilogues: activation / adaLN gate after the bias
+        // an opaque per-tile copy of the lane id: everything the epilogue derives from it would otherwise be
+        // hoisted out of the persistent tile loop and held in registers through the K loop (spills)
+        int elane = lane;
+        asm volatile("" : "+v"(elane));
+        const int el31 = elane & 31, ehalf = elane >> 5;
+        char* const wst = smem + (xbuf ? STAGE : 0) + wave * (32 * RSO);
+        const int nw0 = en0 + wn * WBN;                    // first packed weight row of this wave
+        const int nout0 = GEGLU ? (nw0 >> 1) : nw0;
+        const int mw0 = em0 + wm * (BM / WM);
+        // byte offset of read-back piece `it` of slab i in the output (and residual) tensor; out-of-range
+        // rows / columns get an out-of-bounds buffer offset: loads return 0, stores are dropped -- no branches
+        auto out_off = [&](int ln, int i, int it) -> unsigned {
+            const int idx = ln + it * 64;
+            const int row = idx / CPR, c = idx - row * CPR;
+            const int m = mw0 + i * 32 + row, ncol = nout0 + c * VEC;
+            const bool ok = idx < 32 * CPR && m < p.M && ncol < Nout;
+            return ok ? ((unsigned)m * (unsigned)p.ldo + (unsigned)ncol) * (unsigned)ES : OOB;
+        };
+        // residual prefetch: slab i's 16-byte pieces are requested before slab i is transposed, so the HBM latency
+        // hides under the register phase instead of serialising the stores (at most 10 pieces in flight per lane:
+        // the f32 parity mode would spill with all 20)
+        constexpr int PF0 = TM > 1 ? (NIT + 1) / 2 : (NIT < 10 ? NIT : 10);
+        u32x4 rres[TM][NIT];
+        auto prefetch = [&](int i, int it0, int it1) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int mrow0 = m0 + wm * (BM / WM) + i * 32;
-        // residual prefetch: every 16-byte piece this lane will add is requested before the slab is
-        // transposed, so the HBM latency hides under the register phase instead of serialising the stores
-        V16 rres[NIT];
-        if (has_res) {
+            for (int it = 0; it < NIT; ++it)
+                if (it >= it0 && it < it1)
+                    rres[i][it] = __builtin_amdgcn_raw_buffer_load_b128(rR, (int)out_off(elane, i, it), 0, 0);
+        };
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            __builtin_amdgcn_sched_barrier(0);      // keep slab i+1's loads from being hoisted above slab i (spills)
+            if (has_res) prefetch(i, 0, PF0);
+            __builtin_amdgcn_sched_barrier(0);
+            // register phase: bias (f32, before the one rounding to T) and the D^T -> row-major transpose through LDS
+            const bool odd_half = p.bias2 && (((mw0 + i * 32 + el31) / p.rows_per_batch) & 1);
+#pragma unroll
+            for (int j = 0; j < TN; j += (GEGLU ? 2 : 1)) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+                    if (GEGLU) {
+                        // packed weight rows alternate 32-row blocks [h-block, g-block]
+                        const int nh = nw0 + j * 32 + 8 * g + 4 * ehalf;
+                        f32x4 bh = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+                        if (p.bias && nh < p.N) {
+                            bh = *reinterpret_cast<const f32x4*>(p.bias + nh);
+                            bg = *reinterpret_cast<const f32x4*>(p.bias + nh + 32);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = (acc[i][j][4 * g + e] + bh[e]) * gelu_erf(acc[i][j + 1][4 * g + e] + bg[e]);
+                    } else {
+                        const int nb = nw0 + j * 32 + 8 * g + 4 * ehalf;
+                        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                        if (p.bias && nb < p.N) {
+                            b4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
+                            if (p.bias2) {
+                                const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.bias2 + nb);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) b4[e] = odd_half ? c4[e] : b4[e];
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + b4[e];
+                    }
+                    const int col = (GEGLU ? (j >> 1) : j) * 32 + 8 * g + 4 * ehalf;
+                    char* dst = wst + el31 * RSO + col * ES;
+                    if constexpr (sizeof(T) == 2) {
+                        bf16x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = (bf16)v[e];
+                        *reinterpret_cast<bf16x4*>(dst) = pk;
+                    } else {
+                        f32x4 pk = {v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(dst) = pk;
+                    }
+                }
+            }
+            if (has_res && PF0 < NIT) prefetch(i, PF0, NIT);
+            // read-back phase (same wave: LDS operations of one wave execute in order).  The store offsets are
+            // re-derived from a fresh opaque lane id rather than kept in registers since the prefetch.
+            int slane = lane;
+            asm volatile("" : "+v"(slane));
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int idx = lane + it * 64;
+                const int idx = slane + it * 64;
                 const int row = idx / CPR, c = idx - row * CPR;
-                const int m = mrow0 + row, ncol = c * VEC;
-                if (idx < 32 * CPR && m < p.M && nout0 + ncol < Nout)
-                    rres[it] = *reinterpret_cast<const V16*>(res + (size_t)m * p.ldo + nout0 + ncol);
-            }
-        }
-        // register phase: bias (f32, before the one rounding to T) and the D^T -> row-major transpose through LDS
-        const bool odd_half = p.bias2 && (((mrow0 + l31) / p.rows_per_batch) & 1);
-#pragma unroll
-        for (int j = 0; j < TN; j += (GEGLU ? 2 : 1)) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4];
-                if (GEGLU) {
-                    // packed weight rows alternate 32-row blocks [h-block, g-block]
-                    const int nh = nw0 + j * 32 + 8 * g + 4 * half;
-                    f32x4 bh = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
-                    if (p.bias && nh < p.N) {
-                        bh = *reinterpret_cast<const f32x4*>(p.bias + nh);
-                        bg = *reinterpret_cast<const f32x4*>(p.bias + nh + 32);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = (acc[i][j][4 * g + e] + bh[e]) * gelu_erf(acc[i][j + 1][4 * g + e] + bg[e]);
-                } else {
-                    const int nb = nw0 + j * 32 + 8 * g + 4 * half;
-                    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-                    if (p.bias && nb < p.N) {
-                        b4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
-                        if (p.bias2) {
-                            const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.bias2 + nb);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) b4[e] = odd_half ? c4[e] : b4[e];
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + b4[e];
-                }
-                const int col = (GEGLU ? (j >> 1) : j) * 32 + 8 * g + 4 * half;
-                char* dst = wst + l31 * RSO + col * ES;
-                if constexpr (sizeof(T) == 2) {
-                    bf16x4 pk;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = (bf16)v[e];
-                    *reinterpret_cast<bf16x4*>(dst) = pk;
-                } else {
-                    f32x4 pk = {v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<f32x4*>(dst) = pk;
-                }
-            }
-        }
-        // read-back phase (same wave: LDS operations of one wave execute in order)
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = lane + it * 64;
-            const int row = idx / CPR, c = idx - row * CPR;
-            const int m = mrow0 + row, ncol = c * VEC;
-            if (idx < 32 * CPR && m < p.M && nout0 + ncol < Nout) {
-                const size_t o = (size_t)m * p.ldo + nout0 + ncol;
-                const V16 t = *reinterpret_cast<const V16*>(wst + row * RSO + c * 16);
-                if (!has_res && !slow) {                 // plain projection: LDS -> HBM copy
-                    *reinterpret_cast<V16*>(out + o) = t;
+                const unsigned off = out_off(slane, i, it);
+                // rows beyond the slab (idx >= 32*CPR) read a neighbouring wave's LDS slab; their store is dropped
+                const int rrow = row < 32 ? row : 31;
+                const V16 t = *reinterpret_cast<const V16*>(wst + rrow * RSO + c * 16);
+                if (!SLOW && !has_res) {                 // plain projection: LDS -> HBM copy
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rO, (int)off, 0, 0);
                     continue;
                 }
                 float v[VEC];
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v[e] = (float)t[e];
-                if (p.act == 1) {
+                if (SLOW && p.act == 1) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {      // tanh-GELU: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
                         const float x = v[e], u = 0.7978845608028654f * fmaf(0.044715f * x * x, x, x);
@@ -412,35 +443,57 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                         v[e] = 0.5f * x * (1.0f + (1.0f - 2.0f / (ex + 1.0f)));
                     }
                 }
-                if (p.gate) {
-                    const float* gsel = (p.gate2 && ((m / p.rows_per_batch) & 1)) ? p.gate2 : p.gate;
+                if (SLOW && p.gate) {
+                    const int m = mw0 + i * 32 + rrow, ncol = nout0 + c * VEC;
+                    if (ncol < Nout) {
+                        const float* gsel = (p.gate2 && ((m / p.rows_per_batch) & 1)) ? p.gate2 : p.gate;
 #pragma unroll
-                    for (int e = 0; e < VEC; e += 4) {
-                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gsel + nout0 + ncol + e);
+                        for (int e = 0; e < VEC; e += 4) {
+                            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gsel + ncol + e);
 #pragma unroll
-                        for (int f = 0; f < 4; ++f) v[e + f] *= g4[f];
+                            for (int f = 0; f < 4; ++f) v[e + f] *= g4[f];
+                        }
                     }
                 }
                 if (has_res) {
+                    const V16 r = __builtin_bit_cast(V16, rres[i][it]);
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) v[e] += (float)rres[it][e];
+                    for (int e = 0; e < VEC; ++e) v[e] += (float)r[e];
                 }
                 V16 o16;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) o16[e] = (T)v[e];
-                *reinterpret_cast<V16*>(out + o) = o16;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o16), rO, (int)off, 0, 0);
             }
         }
+        if (!more) break;
+        // the staging state was dead during the epilogue (registers!): re-derive it for the K loop.  The opaque
+        // copy keeps the compiler from holding the pre-epilogue values live across the epilogue instead.
+        vb = nvb;
+        asm volatile("" : "+s"(vb));
+        setup(vb);
+        derive(0);
+        b0 = xbuf ^ 1;
     }
 }
 
-template <typename T, int BM, int BN, int MODE, bool GEGLU, int WM = 4, int WN = 1, int NST = 2>
-int launch_one(const GemmArgs& a, hipStream_t s) {
+int cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+    }
+    return n;
+}
+
+template <typename T, int BM, int BN, int MODE, bool GEGLU, int WM, int WN, int EK>
+int launch_ek(const GemmArgs& a, hipStream_t s) {
     constexpr int NW = WM * WN;
-    constexpr int LDS = gemm_lds_bytes<T, BM, BN, GEGLU, WM, WN, NST>();
+    constexpr int LDS = gemm_lds_bytes<T, BM, BN, GEGLU, WM, WN>();
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_done = false;   // one handle per device / one host thread per handle
-    auto kern = gemm_kernel<T, BM, BN, MODE, GEGLU, WM, WN, NST>;
+    auto kern = gemm_kernel<T, BM, BN, MODE, GEGLU, WM, WN, EK>;
     if (!attr_done) {
         DSIM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_done = true;
@@ -458,11 +511,24 @@ int launch_one(const GemmArgs& a, hipStream_t s) {
         if (a.A1) a1b = (size_t)a.M * a.C1 * es;
     }
     const size_t wb = (size_t)a.N * a.K * es;
-    if (a0b >= 0x7fffffffull || a1b >= 0x7fffffffull || wb >= 0x7fffffffull) return DSIM_ERR_INVALID;
-    g.a0_bytes = (unsigned)a0b; g.a1_bytes = (unsigned)a1b; g.w_bytes = (unsigned)wb;
-    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(NW * 64), LDS, s, g, tilesN);
+    const size_t ob = (size_t)a.M * a.ldo * es;        // output (and residual) extent: rows are ldo elements apart
+    if (a0b >= 0x7fffffffull || a1b >= 0x7fffffffull || wb >= 0x7fffffffull || ob >= 0x7fffffffull) return DSIM_ERR_INVALID;
+    g.a0_bytes = (unsigned)a0b; g.a1_bytes = (unsigned)a1b; g.w_bytes = (unsigned)wb; g.out_bytes = (unsigned)ob;
+    // persistent grid: as many workgroups as stay resident (LDS-limited), a multiple of 8 so a workgroup keeps its XCD
+    const int ntiles = tilesM * tilesN;
+    const int resident = ((cu_count() * (LDS <= 80 * 1024 ? 2 : 1)) / 8) * 8;
+    const int grid = ntiles <= resident || resident < 8 || !g_gemm_persistent ? ntiles : resident;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, s, g, tilesN, ntiles);
     DSIM_HIP_CHECK(hipGetLastError());
     return DSIM_OK;
+}
+
+template <typename T, int BM, int BN, int MODE, bool GEGLU, int WM = 4, int WN = 1, bool SLOW = false>
+int launch_one(const GemmArgs& a, hipStream_t s) {
+    if constexpr (SLOW) return launch_ek<T, BM, BN, MODE, GEGLU, WM, WN, EK_SLOW>(a, s);
+    if constexpr (!GEGLU)
+        if (a.epi == EPI_RESIDUAL) return launch_ek<T, BM, BN, MODE, GEGLU, WM, WN, EK_RES>(a, s);
+    return launch_ek<T, BM, BN, MODE, GEGLU, WM, WN, EK_PLAIN>(a, s);
 }
 
 int check_args(const GemmArgs& a, int BK) {
@@ -483,6 +549,9 @@ int launch_typed(const GemmArgs& a, hipStream_t s) {
     if (st != DSIM_OK) return st;
     int bm, bn;
     gemm_tile_choice(a, &bm, &bn);
+    const bool slow = a.act != 0 || a.gate != nullptr;     // DiT linears only
+    if (slow && (a.mode != GEMM_LINEAR || a.epi == EPI_GEGLU)) return DSIM_ERR_INVALID;
+    if (slow && bm == 256 && a.N % 256) bm = 128;          // the SLOW instantiations are 256x256 and 128x128
     const bool big = bm == 256, n160 = bn == 160;
     (void)big;
     if constexpr (sizeof(T) == 2) {
@@ -492,10 +561,12 @@ int launch_typed(const GemmArgs& a, hipStream_t s) {
             if (a.mode == GEMM_CONV3)
                 return bn == 320 ? launch_one<T, 256, 320, GEMM_CONV3, false, 4, 2>(a, s)
                                  : launch_one<T, 256, 256, GEMM_CONV3, false, 4, 2>(a, s);
+            if (slow) return launch_one<T, 256, 256, GEMM_LINEAR, false, 4, 2, true>(a, s);
             return bn == 320 ? launch_one<T, 256, 320, GEMM_LINEAR, false, 4, 2>(a, s)
                              : launch_one<T, 256, 256, GEMM_LINEAR, false, 4, 2>(a, s);
         }
     }
+    if (slow) return launch_one<T, 128, 128, GEMM_LINEAR, false, 4, 1, true>(a, s);
     if (a.epi == EPI_GEGLU) return launch_one<T, 128, 128, GEMM_LINEAR, true>(a, s);
     if (a.mode == GEMM_CONV3)
         return n160 ? launch_one<T, 128, 160, GEMM_CONV3, false>(a, s) : launch_one<T, 128, 128, GEMM_CONV3, false>(a, s);

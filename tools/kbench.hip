@@ -83,6 +83,8 @@ static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H,
     const int forces[3] = {128, 256, 0};
     for (int v = 0; v < 3; ++v) {
         g_force_bm = forces[v];
+        g_gemm_persistent = 1;
+        if (v == 0 && getenv("KB_NOPERSIST")) { g_force_bm = 0; g_gemm_persistent = 0; }   // column 1 = auto tiles, one tile per workgroup
         msv[v] = t.run([&] { st = launch_gemm(g, DSIM_BF16, 0); }, iters);
     }
     int bm, bn;

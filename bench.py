@@ -41,8 +41,11 @@ def rocprof_name(fam: str) -> str:
         mode = "1" if p[3] == "conv3" else "0"
         geglu = "true" if fam.endswith("_geglu") else "false"
         wn = "2" if bm == "256" else "1"          # 256-row tiles run 8 waves as 4x2, 128-row tiles 4x1
-        return f"gemm_kernel<{t}, {bm}, {bn}, {mode}, {geglu}, 4, {wn}, 2>"
-    return fam
+        ek = "1" if fam.endswith("_res") else "0"  # epilogue kind template argument: 0 plain, 1 residual
+        return f"gemm_kernel<{t}, {bm}, {bn}, {mode}, {geglu}, 4, {wn}, {ek}>"
+    if p[0] == "attention":
+        return f"attn_kernel<{'__bf16' if p[1] == 'bf16' else 'float'}, {p[2][1:]}>"
+    return fam           # groupnorm / layernorm families span several kernel symbols
 
 
 def pmc_traffic(kernel: str):
@@ -59,6 +62,20 @@ def pmc_traffic(kernel: str):
             continue
         if kernel in d:
             return d[kernel]["hbm_bytes_per_launch"]
+    return None
+
+
+def pmc_mfma_util(kernel: str):
+    """MFMA utilisation of `kernel` (SQ_VALU_MFMA_BUSY_CYCLES / (active cycles x 1024 SIMDs)) from the newest
+    committed PMC summary profiles/rNN_pmc_mfma.json, or None."""
+    import glob
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if kernel in d:
+            return d[kernel]["mfma_util"]
     return None
 
 
@@ -243,7 +260,22 @@ def main():
                                "frac": round(ach / peak, 4), "traffic": pmc_traffic(rocprof_name(dom)),
                                "kernel": rocprof_name(dom),
                                "launches_per_step": n, "avg_launch_ms": round(ms / n, 4),
-                               "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2)}
+                               "algorithmic_gflop_per_launch": round(fl / n / 1e9, 2),
+                               "mfma_util_pmc": pmc_mfma_util(rocprof_name(dom))}
+            # the same figures for the next kernels by time (MFMA-bound: TFLOP/s of 2500; HBM-bound: GB/s of 8000)
+            tops = []
+            for name in sorted(fam, key=lambda n_: -fam[n_][3])[:6]:
+                n_, fl_, by_, ms_ = fam[name]
+                if fl_:
+                    a_ = fl_ / (ms_ * 1e-3) / 1e12
+                    tops.append({"kernel": rocprof_name(name), "bound": "mfma", "achieved": round(a_, 1), "peak": peak,
+                                 "unit": "TFLOP/s", "frac": round(a_ / peak, 4), "ms_per_step": round(ms_, 3),
+                                 "mfma_util_pmc": pmc_mfma_util(rocprof_name(name))})
+                else:
+                    a_ = by_ / (ms_ * 1e-3) / 1e9
+                    tops.append({"kernel": rocprof_name(name), "bound": "hbm", "achieved": round(a_, 1), "peak": 8000.0,
+                                 "unit": "GB/s", "frac": round(a_ / 8000.0, 4), "ms_per_step": round(ms_, 3)})
+            out["roofline_top_kernels"] = tops
             out["kernel_breakdown_ms_per_step"] = {
                 k_: {"n": v_[0], "ms": round(v_[3], 3),
                      **({"tflops": round(v_[1] / (v_[3] * 1e-3) / 1e12, 1)} if v_[1] else

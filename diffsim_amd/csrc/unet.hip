@@ -76,7 +76,8 @@ struct Walk {
             int bm, bn;
             gemm_tile_choice(g, &bm, &bn);
             const std::string nm = std::string("gemm_") + dtn() + "_" + std::to_string(bm) + "x" + std::to_string(bn) +
-                                   (g.mode == GEMM_CONV3 ? "_conv3" : "_linear") + (g.epi == EPI_GEGLU ? "_geglu" : "");
+                                   (g.mode == GEMM_CONV3 ? "_conv3" : "_linear") +
+                                   (g.epi == EPI_GEGLU ? "_geglu" : (g.epi == EPI_RESIDUAL ? "_res" : ""));   // one family per kernel symbol
             const double e = (double)es();
             const double outc = g.epi == EPI_GEGLU ? g.N / 2 : g.N;
             pbegin(nm, 2.0 * g.M * (double)g.N * g.K,

@@ -2,12 +2,15 @@
 """Turn the rocprofv3 output that a gpurun call merged into gpurun_out/ into the small, tracked
 summaries under profiles/ (gpurun_out/ is scratch).
 
-  python profiles/summarize.py r01 gpurun_out/prof_r1_trace gpurun_out/prof_r1_fetch gpurun_out/prof_r1_write
+  python profiles/summarize.py r01 gpurun_out/prof_r1_trace gpurun_out/prof_r1_fetch gpurun_out/prof_r1_write [gpurun_out/prof_r1_mfma]
 
 Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, one row per kernel) and
 profiles/<tag>_pmc_hbm.json (per kernel: launches, FETCH_SIZE and WRITE_SIZE per launch in KB as the
 counters report them, and HBM bytes per launch with the gfx950 correction of
 MI355X_MICROARCH.md section HBM: FETCH_SIZE counts half the bytes of wide coalesced reads -> x2).
+With the optional fifth argument (a `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` pass) it also writes
+profiles/<tag>_pmc_mfma.json: per kernel, MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs), with
+cycles = GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs), i.e. at the clock the kernel actually ran at.
 """
 import collections
 import csv
@@ -78,6 +81,23 @@ def main():
                   "write_size_kb_per_launch": round(wk, 1),
                   "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024)}
     json.dump(out, open(os.path.join(HERE, f"{tag}_pmc_hbm.json"), "w"), indent=1, sort_keys=True)
+    if len(sys.argv) > 5:
+        f = glob.glob(os.path.join(sys.argv[5], "**", "*counter_collection.csv"), recursive=True)[0]
+        rr = list(csv.DictReader(open(f)))
+        dm3 = demangle(sorted({r["Kernel_Name"] for r in rr}))
+        acc = collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in rr:
+            e = acc[short(dm3[r["Kernel_Name"]])]
+            e[r["Counter_Name"]] += float(r["Counter_Value"])
+            e["n_" + r["Counter_Name"]] += 1
+        mf = {}
+        for k, e in acc.items():
+            n = max(e["n_GRBM_GUI_ACTIVE"], 1)
+            cyc = e["GRBM_GUI_ACTIVE"] / 8.0 / n
+            busy = e["SQ_VALU_MFMA_BUSY_CYCLES"] / max(e["n_SQ_VALU_MFMA_BUSY_CYCLES"], 1)
+            mf[k] = {"launches": int(n), "cycles_per_launch": int(cyc), "mfma_busy_cycles_per_launch": int(busy),
+                     "mfma_util": round(busy / (cyc * 1024.0), 4) if cyc else None}
+        json.dump(mf, open(os.path.join(HERE, f"{tag}_pmc_mfma.json"), "w"), indent=1, sort_keys=True)
     print("wrote", tag)
 
 

@@ -191,3 +191,40 @@ def test_pair_score_batched_indices_and_determinism(eng):
     # linearity-style property: swapping roles leaves the symmetric score unchanged
     s3 = eng.pair_score(q, k, v, ib, ia, H, "cosine")
     assert torch.allclose(s1, s3, atol=1e-6)
+
+
+# ---- persistent GEMM: more tiles than resident workgroups, ragged last row tile --------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,res", [(256 * 530 + 77, 320, 320, True),      # 256x320 tiles (bf16), 531 tiles > 256 WGs
+                                       (128 * 1100 + 5, 160, 64, False),      # 128x160 tiles, 1101 tiles > 512 WGs
+                                       (256 * 300 + 1, 512, 128, True)])      # 256x256 tiles, 2 column tiles
+def test_linear_many_tiles_per_workgroup(eng, dtype, M, N, K, res):
+    """Each persistent workgroup walks several tiles (stage prefetch under the epilogue, LDS buffer parity carried
+    across tiles, ragged last tile): every row of the output is checked against torch on a strided sample plus the
+    whole ragged tail."""
+    g = torch.Generator().manual_seed(N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    got = eng.op_linear(_dev(x, dtype), _dev(w), _dev(b), _dev(r, dtype) if res else None).float().cpu()
+    rows = torch.cat([torch.arange(0, M, 97), torch.arange(M - 300, M)])
+    want = F.linear(_q(x[rows], dtype), _q(w, dtype), b) + (_q(r[rows], dtype) if res else 0)
+    _close(got[rows], want, dtype)
+    assert torch.isfinite(got).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_many_tiles_per_workgroup(eng, dtype):
+    """3x3 conv, 64 -> 320 channels at 64x64, 20 images: 320 row tiles of 256 (bf16) / 640 of 128 (f32) per column tile."""
+    B, H, W, Cin, Cout = 20, 64, 64, 64, 320
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(B, H, W, Cout, generator=g)
+    got = eng.op_conv3x3(_dev(x, dtype), _dev(w), _dev(b), _dev(r, dtype)).float().cpu()
+    sel = [0, 7, 19]
+    want = F.conv2d(_q(x[sel], dtype).permute(0, 3, 1, 2), _q(w, dtype), b, padding=1).permute(0, 2, 3, 1) + _q(r[sel], dtype)
+    _close(got[sel], want, dtype)
+    assert torch.isfinite(got).all()

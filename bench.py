@@ -296,9 +296,18 @@ def main():
             tc = time.perf_counter()
             so = R.diffsim_latents(unet, zA, zB, noise[2], noise[3], S.make_context(cfg), 600, "up_blocks", 0, "cosine")
             cpu_s = time.perf_counter() - tc
+            # the schedule the reference itself runs (diffsim_pipeline.py:213-221): the FULL U-Net to conv_out,
+            # batch 1, nothing cached -- same scores, about twice the work
+            tc = time.perf_counter()
+            so_full = R.diffsim_latents(unet, zA, zB, noise[2], noise[3], S.make_context(cfg), 600, "up_blocks", 0, "cosine",
+                                        full=True)
+            cpu_full_s = time.perf_counter() - tc
             out["cpu_baseline"] = {"value": round(1.0 / cpu_s, 5), "unit": "pairs/s", "cores": torch.get_num_threads(),
                                    "kind": "port", "sample": "1 pair (pair 0 of the batch), fp32 torch CPU oracle, "
-                                   "U-Net truncated at the tap, host cpu_count=%d" % os.cpu_count()}
+                                   "U-Net truncated at the tap, host cpu_count=%d" % os.cpu_count(),
+                                   "reference_schedule_value": round(1.0 / cpu_full_s, 5),
+                                   "reference_schedule": "same pair, full U-Net to conv_out as diffsim_pipeline.py:213 runs it "
+                                                         "(score %.6f)" % float(so_full)}
             out["parity_pair0"] = {"gpu": float(scores[0]), "cpu_oracle": float(so),
                                    "abs_err": abs(float(scores[0]) - float(so))}
         print(json.dumps(out), flush=True)

@@ -47,7 +47,11 @@ struct Walk {
     bool tapped = false;
 
     size_t es() const { return dtype_size(h->dt); }
-    void* alloc_act(size_t elems) { return ar->alloc(elems * es()); }
+    size_t max_tensor = 0;      // largest single activation (bytes): the kernels address tensors with 32-bit offsets
+    void* alloc_act(size_t elems) {
+        if (elems * es() > max_tensor) max_tensor = elems * es();
+        return ar->alloc(elems * es());
+    }
 
 #define WGET(var, key)                                   \
     const Packed* var = h->find(key);                    \
@@ -548,6 +552,7 @@ size_t dsim_unet_workspace_bytes(const dsim_unet* hc, int n_images) {
     Arena ar;
     Walk w{h, &ar, nullptr, 2 * n_images, false};
     if (w.go(nullptr, nullptr, 0.f, 0.f, nullptr) != DSIM_OK) return 0;
+    if (w.max_tensor >= 0x7fffffffull) return 0;      // a >= 2 GiB activation: the batch does not fit one call
     return ar.peak + 256;
 }
 

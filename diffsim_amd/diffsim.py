@@ -120,6 +120,7 @@ class DiffSim:
         n = latA.shape[0]
         eng = self.engine(target_block, target_layer)
         out = torch.empty(n, dtype=torch.float32, device=self.device)
+        batch_pairs = max(1, min(batch_pairs, eng.max_images() // 2))      # every activation must stay < 2 GiB
         for i0 in range(0, n, batch_pairs):
             i1 = min(n, i0 + batch_pairs)
             m = i1 - i0

@@ -169,6 +169,28 @@ class UNetEngine:
     def workspace_bytes(self, n_images: int) -> int:
         return int(self.L.dsim_unet_workspace_bytes(self._h, n_images))
 
+    def max_images(self, upper: int = 4096) -> int:
+        """Largest n_images one qkv() call accepts (every activation < 2 GiB); bisection over the dry-run planner,
+        cached (it depends on the graph only)."""
+        if getattr(self, "_max_images", None) is not None:
+            return self._max_images
+        self._max_images = self._max_images_search(upper)
+        return self._max_images
+
+    def _max_images_search(self, upper: int) -> int:
+        if self.workspace_bytes(1) == 0:
+            return 0
+        lo, hi = 1, upper
+        if self.workspace_bytes(hi):
+            return hi
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if self.workspace_bytes(mid):
+                lo = mid
+            else:
+                hi = mid
+        return lo
+
     def qkv(self, latents: torch.Tensor, noise: torch.Tensor, sqrt_abar: float, sqrt_1m_abar: float,
             ctx: torch.Tensor, out: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None):
         """latents/noise (n,Cin,s,s) f32 cuda; ctx (2,L,Dc) f32 cuda -> q,k,v each
@@ -184,6 +206,9 @@ class UNetEngine:
             raise _lib.DsimError("ctx must be (2, ctx_len, cross_attention_dim)")
         with torch.cuda.device(self.device):
             need = self.workspace_bytes(n)
+            if need == 0:
+                raise _lib.DsimError(f"{n} images do not fit one call (an activation would reach 2 GiB): at most "
+                                     f"{self.max_images()} images per call for this graph")
             if self._ws is None or self._ws.numel() < need:
                 self._ws = None
                 self._graphs.clear()                 # captured graphs hold the old arena's addresses

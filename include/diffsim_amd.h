@@ -109,6 +109,9 @@ int  dsim_unet_set_timestep(dsim_unet* h, int t, void* stream);
  * embeddings; every ResnetBlock2D bias is prepared once per half. */
 int  dsim_unet_set_conditioning(dsim_unet* h, int t, const float* text_embeds, const float* time_ids, void* stream);
 
+/* Bytes of workspace one dsim_unet_qkv call over n_images needs; 0 when the call is impossible: handle not
+ * finalized, or some activation of that batch would reach 2 GiB (tensors are addressed with 32-bit offsets) --
+ * split the batch then. */
 size_t dsim_unet_workspace_bytes(const dsim_unet* h, int n_images);
 
 /* One noised U-Net forward to the tap for n_images latents, each duplicated for

@@ -252,6 +252,27 @@ def test_sd15_full_size_fp32_and_bf16_pairs():
     got32 = _scorer(cfg, sd, torch.float32).score_latent_pairs(zA, zB, n[2], n[3], ctx).cpu()
     for s, w in zip(got32.tolist(), want):
         assert _rel(s, w) <= REL_F32, (s, w)
-    got16 = _scorer(cfg, sd, torch.bfloat16).score_latent_pairs(zA, zB, n[2], n[3], ctx).cpu()
+    sc16 = _scorer(cfg, sd, torch.bfloat16)
+    got16 = sc16.score_latent_pairs(zA, zB, n[2], n[3], ctx).cpu()
     for s, w in zip(got16.tolist(), want):
         assert abs(s - w) <= 5e-3, (s, w)
+    # the 2 GiB-per-tensor bound of the 32-bit buffer offsets: the planner reports it, qkv refuses it loudly
+    from diffsim_amd import _lib
+    eng = sc16.engine("up_blocks", 0)
+    mx = eng.max_images()
+    assert 64 <= mx < 512 and eng.workspace_bytes(mx) > 0 and eng.workspace_bytes(mx + 1) == 0
+    big = torch.zeros(mx + 1, 4, 64, 64, device="cuda")
+    with pytest.raises(_lib.DsimError):
+        eng.qkv(big, big, 1.0, 0.0, ctx.cuda())
+
+
+def test_batch_is_split_at_the_2gib_tensor_bound(tiny_env):
+    """workspace_bytes() is 0 for a batch whose activations would reach 2 GiB; qkv() refuses it loudly and
+    score_latent_pairs() splits the batch instead (same scores as small batches)."""
+    from diffsim_amd import _lib
+    ds = _scorer(C.TINY, tiny_env["sd"], torch.bfloat16)
+    eng = ds.engine("up_blocks", 0)
+    mx = eng.max_images()
+    assert mx >= 2 and eng.workspace_bytes(mx) > 0
+    if mx < 4096:
+        assert eng.workspace_bytes(mx + 1) == 0

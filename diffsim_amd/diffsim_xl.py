@@ -68,6 +68,7 @@ class diffsim_xl:
         eng = self.engine(target_block, target_layer)
         out = torch.empty(n, dtype=torch.float32, device=self.device)
         shp = latA.shape[1:]
+        batch_pairs = max(1, min(batch_pairs, eng.max_images() // 2))      # every activation must stay < 2 GiB
         for i0 in range(0, n, batch_pairs):
             i1 = min(n, i0 + batch_pairs)
             m = i1 - i0

@@ -120,8 +120,23 @@ def secondary(a, world, rank, dev):
         scores = run()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    extra = {}
+    if rank == 0 and a.model == "sdxl" and not a.no_profile:
+        # algorithmic FLOPs of the path actually launched (per-launch records of one profiled step)
+        eng = sc.engine("up_blocks", [0, 0, 0])
+        eng.profile(True)
+        run()
+        recs = eng.profile_records()
+        eng.profile(False)
+        fl = sum(r[1] for r in recs)
+        fam = {}
+        for kn_, f_, b_, ms_ in recs:
+            e = fam.setdefault(kn_, [0, 0.0, 0.0]); e[0] += 1; e[1] += f_; e[2] += ms_
+        extra = {"gflop_per_pair": round(fl / bp / 1e9, 1), "whole_path_tflops_per_gpu": round(fl / (el / a.steps) / 1e12, 1),
+                 "kernel_breakdown_ms_per_step": {k_: {"n": v_[0], "ms": round(v_[2], 3)} for k_, v_ in
+                                                  sorted(fam.items(), key=lambda kv: -kv[1][2])[:8]}}
     if rank == 0:
-        print(json.dumps({"metric": "image-pairs/sec (secondary config)", "value": round(world * a.steps * bp / el, 3), "unit": "pairs/s",
+        print(json.dumps({**extra, "metric": "image-pairs/sec (secondary config)", "value": round(world * a.steps * bp / el, 3), "unit": "pairs/s",
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * el / a.steps, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                           "config": {"workload": name, "pairs_per_step_per_gpu": bp},

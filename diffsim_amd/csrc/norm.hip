@@ -158,12 +158,22 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
     const int trow = tid / tpr, tcol = tid - trow * tpr;
     const int b = blockIdx.y;
     const int cpg = C / groups;
+    // the image's chunks x groups partial pairs: fetched by the whole workgroup in one round trip (a per-group
+    // thread walking them serially cost ~32 dependent L2 round trips before the first row was streamed), then folded
+    // by one thread per group in fixed order
+    extern __shared__ __attribute__((aligned(16))) char smem_apply[];
+    double* fold = reinterpret_cast<double*>(smem_apply);
+    {
+        const double* src = part + (size_t)b * chunks * groups * 2;
+        const int cnt = chunks * groups * 2;
+        for (int i = tid; i < cnt; i += GN_THREADS) fold[i] = src[i];
+    }
+    __syncthreads();
     if (tid < groups) {
         double a = 0.0, q = 0.0;
         for (int c = 0; c < chunks; ++c) {
-            const double* o = part + (((size_t)b * chunks + c) * groups + tid) * 2;
-            a += o[0];
-            q += o[1];
+            a += fold[(c * groups + tid) * 2];
+            q += fold[(c * groups + tid) * 2 + 1];
         }
         const double n = (double)HW * cpg;
         const double mean = a / n;
@@ -388,11 +398,12 @@ int gn_launch(const void* x0, int C0, const void* x1, int C1, const float* gamma
               int HW, int groups, float eps, int silu, void* scratch, int chunks, int rb, size_t lds, hipStream_t s) {
     hipLaunchKernelGGL((gn_stats_kernel<T, NS, UNR>), dim3(chunks, B), dim3(GN_THREADS), lds, s, (const T*)x0, C0,
                        (const T*)x1, C1, HW, groups, (double*)scratch);
+    const size_t alds = (size_t)chunks * groups * 2 * sizeof(double);       // <= 32 KB
     if (silu)
-        hipLaunchKernelGGL((gn_apply_kernel<T, true, NS, UNR>), dim3(rb, B), dim3(GN_THREADS), 0, s, (const T*)x0, C0,
+        hipLaunchKernelGGL((gn_apply_kernel<T, true, NS, UNR>), dim3(rb, B), dim3(GN_THREADS), alds, s, (const T*)x0, C0,
                            (const T*)x1, C1, gamma, beta, (T*)out, HW, groups, eps, chunks, (const double*)scratch);
     else
-        hipLaunchKernelGGL((gn_apply_kernel<T, false, NS, UNR>), dim3(rb, B), dim3(GN_THREADS), 0, s, (const T*)x0, C0,
+        hipLaunchKernelGGL((gn_apply_kernel<T, false, NS, UNR>), dim3(rb, B), dim3(GN_THREADS), alds, s, (const T*)x0, C0,
                            (const T*)x1, C1, gamma, beta, (T*)out, HW, groups, eps, chunks, (const double*)scratch);
     DSIM_HIP_CHECK(hipGetLastError());
     return DSIM_OK;
@@ -410,7 +421,11 @@ int gn_typed(const void* x0, int C0, const void* x1, int C1, const float* gamma,
     const int chunks = gn_chunks(HW);
     const size_t lds = (size_t)R * C * 2 * sizeof(float);
     if (lds > 64 * 1024) return DSIM_ERR_INVALID;
+    // row blocks per image of the apply pass (no effect on the numbers): about 2048 workgroups in all, so that large
+    // batches amortise each workgroup's statistics fold over more rows and small batches still fill the chip
     int rb = HW / (R * 4);
+    const int want = (2048 + B - 1) / B;
+    if (rb > want) rb = want;
     rb = rb < 1 ? 1 : (rb > 64 ? 64 : rb);
     const int ns = (S + tpr - 1) / tpr;
     if (ns == 1)

@@ -340,14 +340,24 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
         for (int r = 0; r < 16; ++r) o[db][r] *= inv;
 }
 
-// grid (ceil(Nq/128), H, B)
+// grid ceil(Nq/128) * H * B (1-D)
 template <typename T, int D>
 __global__ __launch_bounds__(256, (ACfg<T, D>::WPS)) void attn_kernel(const AttnArgs p, const float scale_log2) {
     typedef ACfg<T, D> C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q = blockIdx.x * 128 + wave * 32 + l31;
+    // 1-D grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs, each with its own L2.  Give every XCD a
+    // contiguous run of logical blocks so that the query blocks of one (batch, head) -- which all re-read the same
+    // K and V -- run on ONE XCD back to back and find them in its L2 (bijective for any grid size).
+    const int nqb = (p.Nq + 127) / 128;
+    int bid = blockIdx.x;
+    if (p.xcd_remap) {
+        const int nwg = gridDim.x, xcd = bid & 7, qq = nwg >> 3, r = nwg & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + slot;
+    }
+    const int qblk = bid % nqb, bh = bid / nqb;
+    const int h = bh % p.H, b = bh / p.H;
+    const int q = qblk * 128 + wave * 32 + l31;
     const int qc = q < p.Nq ? q : p.Nq - 1;
     const T* qrow = (const T*)p.q + ((size_t)b * p.Nq + qc) * p.ldq + h * D;
     QFrags<T, D> qf;
@@ -470,7 +480,7 @@ int launch_attn_d(const AttnArgs& a, hipStream_t s) {
         DSIM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((a.Nq + 127) / 128, a.H, a.B), dim3(256), C::LDS, s, a, scale_log2_of(D));
+    hipLaunchKernelGGL(kern, dim3(((a.Nq + 127) / 128) * a.H * a.B), dim3(256), C::LDS, s, a, scale_log2_of(D));
     DSIM_HIP_CHECK(hipGetLastError());
     return DSIM_OK;
 }

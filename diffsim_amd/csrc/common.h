@@ -106,6 +106,7 @@ struct AttnArgs {
     const void* k = nullptr; const void* v = nullptr; int ldk = 0;   // [Bkv][Nk] rows
     void* out = nullptr; int ldo = 0;
     int B = 0, Bkv = 0, H = 0, Nq = 0, Nk = 0, D = 0;
+    int xcd_remap = 1;                        // 0: plain block order (micro-benchmark A/B only)
 };
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
 size_t pair_score_scratch_bytes(int n_pairs, int B, int H, int N, int D);

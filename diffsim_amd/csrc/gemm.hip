@@ -262,33 +262,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     const int sw = (lane >> 1) & 7;                  // == (row>>1)&7 for row = 32*x + (lane&31)
     const int frow = (lane & 31) * 128;
 
-    auto compute = [&](int buf) {
+    // Fragments are register double-buffered (set kk&1): the ds_reads of sub-step kk+1 are in flight while the MFMAs
+    // of sub-step kk run.  The K loop below is ROTATED by one sub-step: the MFMAs of a K tile's LAST sub-step are
+    // issued after the barrier that ends the tile, right behind the first fragment reads of the NEXT tile -- so the
+    // matrix pipe has register-resident work while those reads (and the barrier skew) are outstanding, instead of
+    // both waves of a SIMD idling on LDS latency at every tile start.
+    Frag fa[2][TM], fb[2][TN];
+    auto load_set = [&](int buf, int kk, int set) {
         const char* sa = smem + (buf ? STAGE + SPARE : 0) + wm * (BM / WM) * 128 + frow;
         const char* sb = smem + (buf ? STAGE + SPARE : 0) + A_BYTES + wn * WBN * 128 + frow;
-        // fragments are register double-buffered: the ds_reads of step kk+1 are in flight while the
-        // MFMAs of step kk run, so only the first read of a K tile exposes LDS latency
-        Frag fa[2][TM], fb[2][TN];
-        auto load_set = [&](int kk, int set) {
-            const int c0 = (sizeof(T) == 2) ? (2 * kk + half) : (4 * kk + 2 * half);
+        const int c0 = (sizeof(T) == 2) ? (2 * kk + half) : (4 * kk + 2 * half);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) load_frag(fa[set][i], sa + i * 32 * 128, c0, sw);
+        for (int i = 0; i < TM; ++i) load_frag(fa[set][i], sa + i * 32 * 128, c0, sw);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) load_frag(fb[set][j], sb + j * 32 * 128, c0, sw);
-        };
-        load_set(0, 0);
+        for (int j = 0; j < TN; ++j) load_frag(fb[set][j], sb + j * 32 * 128, c0, sw);
+    };
+    auto mma_set = [&](int set) {
 #pragma unroll
-        for (int kk = 0; kk < KSUB; ++kk) {
-            if (kk + 1 < KSUB) load_set(kk + 1, (kk + 1) & 1);
-            // pin the order "all reads of step kk+1, then all MFMAs of step kk": left alone, hipcc
-            // sinks each ds_read to just before its MFMA and every MFMA then waits out LDS latency
-            __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    mma(fb[kk & 1][j], fa[kk & 1][i], acc[i][j]);   // D^T: rows = n (registers), cols = m (lane)
-            __builtin_amdgcn_sched_barrier(0);
-        }
+            for (int j = 0; j < TN; ++j)
+                mma(fb[set][j], fa[set][i], acc[i][j]);   // D^T: rows = n (registers), cols = m (lane)
     };
 
     constexpr int ES = sizeof(T);
@@ -316,12 +310,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
         // stage 0 has landed in every wave; every wave is past the previous tile's epilogue (its LDS slabs are free)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        load_set(b0, 0, 0);
         for (int t = 0; t < nk; ++t) {
             const int cur = b0 ^ (t & 1);
             if (t + 1 < nk) stage(t + 1, cur ^ 1);
-            compute(cur);
+#pragma unroll
+            for (int kk = 0; kk + 1 < KSUB; ++kk) {
+                load_set(cur, kk + 1, (kk + 1) & 1);
+                // pin the order "all reads of sub-step kk+1, then all MFMAs of sub-step kk": left alone, hipcc sinks
+                // each ds_read to just before its MFMA and every MFMA then waits out LDS latency
+                __builtin_amdgcn_sched_barrier(0);
+                mma_set(kk & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            __syncthreads();                                    // (also drains this wave's fragment reads of `cur`)
+            if (t + 1 < nk) load_set(cur ^ 1, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_set((KSUB - 1) & 1);                            // the tile's last sub-step, from registers
+            __builtin_amdgcn_sched_barrier(0);
         }
         const int xbuf = b0 ^ ((nk - 1) & 1);          // buffer the last K step read: epilogue scratch = it + spare
         const int em0 = m0, en0 = n0;

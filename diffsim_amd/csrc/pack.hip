@@ -128,6 +128,32 @@ __global__ __launch_bounds__(256) void prep_conv_in_kernel(const float* __restri
         patch[i] = v;
     }
     __syncthreads();
+    if (Cout <= 128) {
+        // narrow outputs (the VAE's 128 channels): the two halves of the workgroup take half of the pixels each
+        // instead of leaving 128 threads idle
+        constexpr int HP = PREP_PIX / 2;
+        const int co = threadIdx.x % 128, pg = threadIdx.x / 128;
+        if (co < Cout) {
+            float acc[HP];
+            const float bv = bias[co];
+#pragma unroll
+            for (int pp = 0; pp < HP; ++pp) acc[pp] = bv;
+            for (int k = 0; k < K; ++k) {
+                const float wv = w[(size_t)k * Cout + co];
+#pragma unroll
+                for (int pp = 0; pp < HP; ++pp) acc[pp] = fmaf(patch[(pg * HP + pp) * K + k], wv, acc[pp]);
+            }
+#pragma unroll
+            for (int pp = 0; pp < HP; ++pp) {
+                const int pix = p0 + pg * HP + pp;
+                if (pix < HW) {
+                    const T v = (T)acc[pp];
+                    for (int d = 0; d < dup; ++d) out[((size_t)(img * dup + d) * HW + pix) * Cout + co] = v;
+                }
+            }
+        }
+        return;
+    }
     for (int co = threadIdx.x; co < Cout; co += 256) {
         float acc[PREP_PIX];
         const float bv = bias[co];

@@ -117,3 +117,33 @@ def test_nights_decision_rule():
     assert Hn.nights_decisions(sl, sr, "mse").tolist() == [0, 1, 0]         # night_main.py:158-159
     assert abs(Hn.nights_accuracy(sl, sr, [1, 0, 1], "cosine") - 200.0 / 3) < 1e-4
     assert Hn.cute_accuracy(sl, sr) == pytest.approx(100.0 / 3)
+
+
+def test_bench_kernel_names_match_the_committed_rocprof_summaries():
+    """bench.py maps its per-launch profile families to the kernel symbols rocprofv3 prints, so that
+    roofline.traffic / mfma_util_pmc come from the committed PMC summaries: every MFMA kernel of the newest
+    committed bench line must be found in the same snapshot's kernel-trace and PMC files."""
+    import csv
+    import glob
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    benches = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench.json")))
+    tag = os.path.basename(benches[-1]).split("_")[0]
+    line = json.load(open(benches[-1]))
+    mf = os.path.join(root, "profiles", f"{tag}_pmc_mfma.json")
+    if not os.path.exists(mf):
+        pytest.skip("snapshot without an MFMA pass")
+    mfma = json.load(open(mf))
+    hbm = json.load(open(os.path.join(root, "profiles", f"{tag}_pmc_hbm.json")))
+    stats = {r["kernel"] for r in csv.DictReader(open(os.path.join(root, "profiles", f"{tag}_kernel_stats.csv")))}
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fams = [k for k in line["kernel_breakdown_ms_per_step"] if k.startswith(("gemm_", "attention_"))]
+    assert fams
+    for fam in fams:
+        name = bench.rocprof_name(fam)
+        assert name in stats, (fam, name)
+        assert name in mfma and name in hbm, (fam, name)
+    assert line["roofline"]["kernel"] in stats
+    assert bench.pmc_traffic(line["roofline"]["kernel"]) and bench.pmc_mfma_util(line["roofline"]["kernel"])

@@ -41,7 +41,9 @@ template <typename T, int D> struct ACfg {
     static constexpr int NDB = (D + 31) / 32;     // 32-wide output blocks over d (PV)
     static constexpr int DPL = NDB * 32;          // LDS columns (zero padded)
     static constexpr bool ONES = D < DPL;         // spare column -> ones column gives the row sum
-    static constexpr int RS = DPL * ES + 16;      // K tile row stride: odd number of 16-B slots (ds_read_b128)
+    // K tile: only the NKS*16 columns QK^T reads (bf16); row stride an odd number of 16-B slots (ds_read_b128)
+    static constexpr int DPLK = (ES == 2) ? NKS * 16 : DPL;
+    static constexpr int RS = DPLK * ES + 16;
     // V tile row stride.  bf16: the transposed reads (ds_read_b64_tr_b16) take, per 32-lane half, a
     // 4-row x 32-column block = 4 rows x 16 dwords; they are conflict-free when the row stride is
     // 16 or 48 dwords mod 64 (four rows tile the 64 banks).  f32: plain ds_read_b32, same as K.
@@ -52,7 +54,8 @@ template <typename T, int D> struct ACfg {
     static constexpr bool PIPE = sizeof(T) == 2;
     static constexpr int LDS = (PIPE ? 4 : 2) * TILE;
     // waves per SIMD the register budget is held to (occupancy hides the serial MFMA/VALU phases)
-    static constexpr int WPS = (sizeof(T) == 2 && DPL <= 64) ? 3 : ((sizeof(T) == 2 && DPL <= 96) ? 2 : 1);
+    // (4 workgroups per CU need <= 40 KB of LDS each: true for d <= 48 now that the K tile is 48 columns wide)
+    static constexpr int WPS = (sizeof(T) == 2 && DPL <= 64) ? (LDS <= 40 * 1024 ? 4 : 3) : ((sizeof(T) == 2 && DPL <= 96) ? 2 : 1);
 };
 
 struct FragF32 { f32x4 lo, hi; };

@@ -10,16 +10,19 @@
 // Data layout: activations token-major [M][C]; weights packed [N][K] with K contiguous
 // (conv: k = tap*Cin + c).  LDS tiles are [rows][128 B] with the 16-B chunk index XOR-swizzled
 // by (row>>1)&7 so that ds_read_b128 fragment reads are bank-conflict free; tiles are filled by
-// LDS-DMA (global_load_lds_dwordx4), whose lane-linear destination means the swizzle is applied
-// to the per-lane SOURCE address.  Zero padding of conv borders and ragged M/N edges comes from
-// pointing those lanes at a 16-byte zero page.
+// LDS-DMA (buffer_load_dwordx4 ... lds through buffer descriptors), whose lane-linear destination
+// means the swizzle is applied to the per-lane SOURCE address.  Zero padding of conv borders and
+// ragged M/N edges comes from an out-of-range buffer offset (the DMA then writes zeros).
+//
+// Schedule (details at gemm_kernel): persistent workgroups, 2-stage LDS ring per K tile, register
+// double-buffered fragments with the K loop rotated by one sub-step, D^T accumulators transposed
+// through wave-private LDS slabs into 16-byte coalesced stores, residual prefetched under the
+// transpose, next tile's first stage in flight under the epilogue.
 #include "common.h"
 
 namespace dsim {
 
-// tile choice: 160-wide tiles when N allows (every SD channel count is a multiple of 160),
-// 256-row tiles once they still give >= one workgroup per CU.
-int g_force_bm = 0;
+int g_force_bm = 0;           // development override (kbench A/B): 128 / 256 force the row tile
 int g_gemm_persistent = 1;   // development override (kbench A/B): 0 = one tile per workgroup
 // Tile choice.  Small problems: 128-row tiles, 4 waves, two workgroups per CU (160-wide when N
 // allows -- every SD channel count is a multiple of 160 -- else 128).  bf16 problems with enough
@@ -60,10 +63,6 @@ template <> struct Vec16T<float> { typedef f32x4 type; };
 
 struct FragF32 { f32x4 lo, hi; };
 
-__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 __device__ __forceinline__ void load_frag(bf16x8& f, const char* row, int c0, int sw) {
     f = *reinterpret_cast<const bf16x8*>(row + ((c0 ^ sw) << 4));
@@ -102,8 +101,6 @@ __device__ __forceinline__ float erf_as(float x) {
     return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
-
-template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 
 // LDS: [stage buffer 0][spare][stage buffer 1].  The epilogue's wave-private transpose slabs live in the buffer the
 // last K step read plus the spare, so the OTHER buffer can already receive the next tile's first K stage while the

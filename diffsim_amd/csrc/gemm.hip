@@ -26,19 +26,21 @@ int g_force_bm = 0;           // development override (kbench A/B): 128 / 256 fo
 int g_gemm_persistent = 1;   // development override (kbench A/B): 0 = one tile per workgroup
 // Tile choice.  Small problems: 128-row tiles, 4 waves, two workgroups per CU (160-wide when N
 // allows -- every SD channel count is a multiple of 160 -- else 128).  bf16 problems with enough
-// 256-row tiles to fill the chip: 256 x 320 (or 256 x 256) tiles, 8 waves as 4 x 2.
+// 256-row tiles to fill the chip: 256 x 320 (or 256 x 256, or 256 x 192 for the DiT widths) tiles, 8 waves as 4 x 2.
 void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn) {
     const bool geglu = a.epi == EPI_GEGLU;
     const bool n320 = !geglu && a.N % 320 == 0, n256 = a.N % 256 == 0;
+    // 192-wide: the DiT widths (1152, 3456) that neither 320 nor 256 divides; linear layers only
+    const bool n192 = !geglu && a.mode == GEMM_LINEAR && !n320 && !n256 && a.N % 192 == 0;
     int want256 = 0;
-    if (n320 || n256) {
-        const int bnb = n320 ? 320 : 256;
+    if (n320 || n256 || n192) {
+        const int bnb = n320 ? 320 : (n256 ? 256 : 192);
         const long tiles = (long)((a.M + 255) / 256) * (a.N / bnb);
         want256 = tiles >= 256;
     }
     if (g_force_bm == 128) want256 = 0;                       // development override (kbench A/B)
-    if (g_force_bm == 256) want256 = (n320 || n256);
-    if (want256) { *bm = 256; *bn = n320 ? 320 : 256; return; }
+    if (g_force_bm == 256) want256 = (n320 || n256 || n192);
+    if (want256) { *bm = 256; *bn = n320 ? 320 : (n256 ? 256 : 192); return; }
     *bm = 128;
     *bn = (a.N % 160 == 0 && !geglu) ? 160 : 128;
 }
@@ -555,7 +557,7 @@ int launch_typed(const GemmArgs& a, hipStream_t s) {
     gemm_tile_choice(a, &bm, &bn);
     const bool slow = a.act != 0 || a.gate != nullptr;     // DiT linears only
     if (slow && (a.mode != GEMM_LINEAR || a.epi == EPI_GEGLU)) return DSIM_ERR_INVALID;
-    if (slow && bm == 256 && a.N % 256) bm = 128;          // the SLOW instantiations are 256x256 and 128x128
+    if (slow && bm == 256 && bn == 320) bm = 128;          // the SLOW instantiations are 256x256, 256x192 and 128x128
     const bool big = bm == 256, n160 = bn == 160;
     (void)big;
     if constexpr (sizeof(T) == 2) {
@@ -565,7 +567,9 @@ int launch_typed(const GemmArgs& a, hipStream_t s) {
             if (a.mode == GEMM_CONV3)
                 return bn == 320 ? launch_one<T, 256, 320, GEMM_CONV3, false, 4, 2>(a, s)
                                  : launch_one<T, 256, 256, GEMM_CONV3, false, 4, 2>(a, s);
-            if (slow) return launch_one<T, 256, 256, GEMM_LINEAR, false, 4, 2, true>(a, s);
+            if (slow) return bn == 192 ? launch_one<T, 256, 192, GEMM_LINEAR, false, 4, 2, true>(a, s)
+                                       : launch_one<T, 256, 256, GEMM_LINEAR, false, 4, 2, true>(a, s);
+            if (bn == 192) return launch_one<T, 256, 192, GEMM_LINEAR, false, 4, 2>(a, s);
             return bn == 320 ? launch_one<T, 256, 320, GEMM_LINEAR, false, 4, 2>(a, s)
                              : launch_one<T, 256, 256, GEMM_LINEAR, false, 4, 2>(a, s);
         }

@@ -103,13 +103,15 @@ def secondary(a, world, rank, dev):
         from diffsim_amd.diffsim_dit import diffsim_DiT
         cfg = C.DIT_XL2
         keys = [k for k in C.dit_param_shapes(cfg) if not (k.startswith("blocks.") and int(k.split(".")[1]) > 13)]
-        sc = diffsim_DiT(256, 600, str(dev), dit_config=cfg, state_dict=S.make_state_dict(cfg, seed=0, keys=keys), torch_dtype=dtype)
+        sc = diffsim_DiT(256, 600, str(dev), dit_config=cfg, state_dict=S.make_state_dict(cfg, seed=0, keys=keys), torch_dtype=dtype,
+                         fp8_attention=a.fp8_attention)
         shp = (1, 4, 32, 32)
         g = torch.Generator("cpu").manual_seed(1234 + rank)
         zA, zB = torch.randn((bp,) + shp[1:], generator=g), torch.randn((bp,) + shp[1:], generator=g)
         n = S.draw_pair_noise(2334, shp)
         run = lambda: sc.score_latent_pairs(zA, zB, n[2], n[3], 13, 600, "cosine", batch_pairs=bp)
-        name = "DiffSim-DiT (DiT-XL/2), synthetic 256px pairs (latents-in), blocks[13] step 600, cosine"
+        name = "DiffSim-DiT (DiT-XL/2), synthetic 256px pairs (latents-in), blocks[13] step 600, cosine" + \
+               (", fp8 (e4m3) MFMA attention" if a.fp8_attention else "")
     zA, zB = zA.to(dev), zB.to(dev)
     n = [t.to(dev) for t in n]
     for _ in range(a.warmup):
@@ -154,6 +156,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--model", choices=["sd15", "sdxl", "dit"], default="sd15",
                     help="sd15 = the headline metric (BASELINE config[1]); sdxl / dit = secondary lines for configs[3], [4]")
+    ap.add_argument("--fp8-attention", action="store_true", help="--model dit only: e4m3 MFMA attention in the DiT blocks (config 5)")
     ap.add_argument("--pixels-in", action="store_true",
                     help="secondary line: include the VAE encoder (512x512 pixels in HBM -> score); the headline "
                          "metric is latents-in")

@@ -83,6 +83,7 @@ SYMBOLS = {
     "dsim_dit_load_weight": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(C.c_int64), _i]),
     "dsim_dit_finalize": (_i, [_vp, _vp]),
     "dsim_dit_set_conditioning": (_i, [_vp, _i, _i, _i, _vp]),
+    "dsim_dit_set_attention": (_i, [_vp, _i]),
     "dsim_dit_workspace_bytes": (_sz, [_vp, _i]),
     "dsim_dit_qkv": (_i, [_vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dsim_pair_score_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
@@ -92,6 +93,7 @@ SYMBOLS = {
     "dsim_op_groupnorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp]),
     "dsim_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
     "dsim_op_attention": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dsim_op_attention_fp8": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None
@@ -110,7 +112,7 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.dsim_version() != 2:
+        if L.dsim_version() != 3:
             raise DsimError("ABI version mismatch")
         _lib = L
     return _lib

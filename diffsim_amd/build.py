@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libdiffsim_amd.so")
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "pack.hip", "unet.hip", "vae.hip", "dit.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "attention_fp8.hip", "pack.hip", "unet.hip", "vae.hip", "dit.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "store.h"), os.path.join(HERE, "..", "include", "diffsim_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -1,0 +1,261 @@
+// fp8 (OCP e4m3) MFMA attention for the DiT graph -- BASELINE.json config 5 ("DiffSim-DiT, fp8 MFMA attention").
+//
+// Same algorithm and tiling as attn_kernel<bf16, D> (attention.hip: a workgroup = 4 waves = 128 query rows of one
+// (batch, head); swapped QK^T so that the softmax is lane-local; online softmax that re-bases only when a row max
+// grew; row sums from a ones row in V^T), with both matmuls on v_mfma_f32_32x32x16_fp8_fp8:
+//   * Q (pre-scaled by log2(e)/sqrt(D)), K and V arrive in bf16 and are rounded to e4m3 on the way into registers /
+//     LDS (v_cvt_pk_fp8_f32, round-to-nearest-even, saturating).  No per-tensor scales: e4m3 is a floating format,
+//     a scale would move the range, not the 3-bit mantissa; |x| <= 448 holds for normalised activations.
+//   * P = exp2(s - m + 7): the accumulators start at -(m - 7), so the probabilities land in (0, 128] where e4m3 has
+//     its full relative precision down to 2^-9 * ... (p/128 >= 2^-16 of the row max survives).  The ones row of V^T
+//     sums the SAME rounded values, so the 2^7 cancels in the final normalisation.
+//   * LDS holds K as [kv][d] bytes and V TRANSPOSED as [d][kv] bytes with the kv order inside each 16-block permuted
+//     to the order the MFMA B operand (the S^T accumulator registers) presents them in, so both operands are plain
+//     ds_read_b64.
+// Accuracy is that of fp8 attention (a few 1e-2 relative on the attention output); it is opt-in
+// (dsim_dit_set_attention) and compared against the fp32 oracle with a stated, looser tolerance in the tests.
+#include "common.h"
+
+namespace dsim {
+namespace {
+
+constexpr int KT8 = 64;                      // kv rows per LDS tile
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int D> struct F8Cfg {
+    static constexpr int NKS = (D + 15) / 16;        // 16-deep k steps over d (QK^T)
+    static constexpr int NDB = D / 32 + 1;           // 32-row blocks of O^T; always leaves row D free for the ones row
+    static constexpr int DPL = NDB * 32;
+    static constexpr int RSK = NKS * 16 + 8;         // K row stride (bytes): 2 (mod 4) dwords -> conflict-free ds_read_b64
+    static constexpr int RSV = KT8 + 8;              // V^T row stride (bytes)
+    static constexpr int TILEK = KT8 * RSK;
+    static constexpr int TILEV = DPL * RSV;
+    static constexpr int TILE = (TILEK + TILEV + 15) & ~15;
+    static constexpr int LDS = 2 * TILE;             // double buffered
+    static constexpr int CPRD = D / 8;               // 16-byte bf16 chunks per row
+    static constexpr int NCH = (KT8 * CPRD + 255) / 256;
+};
+
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d) {
+    int r = 0;
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, r, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+    return (unsigned)r;
+}
+// 8 bf16 (one 16-byte chunk) -> 8 fp8, optionally scaled
+__device__ __forceinline__ long chunk_to_fp8(const u32x4& raw, float sc) {
+    const bf16x8 t = __builtin_bit_cast(bf16x8, raw);
+    const unsigned lo = pack4_fp8((float)t[0] * sc, (float)t[1] * sc, (float)t[2] * sc, (float)t[3] * sc);
+    const unsigned hi = pack4_fp8((float)t[4] * sc, (float)t[5] * sc, (float)t[6] * sc, (float)t[7] * sc);
+    return (long)(((unsigned long)hi << 32) | lo);
+}
+// position of kv row k (inside its 16-block) in the V^T tile: the B operand built from the S^T accumulators
+// carries, for lane half hf, the rows {4hf..4hf+3, 8+4hf..8+4hf+3}; store them contiguously
+__device__ __forceinline__ int vperm(int k) {
+    const int b = (k >> 3) & 1, hf = (k >> 2) & 1, j = k & 3;
+    return (k & ~15) | (8 * hf + 4 * b + j);
+}
+
+// grid ceil(Nq/128) * H * B (1-D, XCD-aware like attn_kernel)
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_fp8_kernel(const AttnArgs p, const float scale_log2) {
+    typedef F8Cfg<D> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int nqb = (p.Nq + 127) / 128;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, qq = nwg >> 3, r = nwg & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + slot;
+    }
+    const int qblk = bid % nqb, bh = bid / nqb;
+    const int h = bh % p.H, b = bh / p.H;
+    const int q = qblk * 128 + wave * 32 + l31;
+    const int qc = q < p.Nq ? q : p.Nq - 1;
+    const bf16* qrow = (const bf16*)p.q + ((size_t)b * p.Nq + qc) * p.ldq + h * D;
+    const size_t kvoff = (size_t)(b % p.Bkv) * p.Nk * p.ldk + h * D;
+    const bf16* kb = (const bf16*)p.k + kvoff;
+    const bf16* vb = (const bf16*)p.v + kvoff;
+    const int ldk = p.ldk, Nk = p.Nk;
+
+    // Q fragments: 8 d-values at d = 16 ks + 8 half, pre-scaled, rounded to fp8
+    long qf[C::NKS];
+#pragma unroll
+    for (int ks = 0; ks < C::NKS; ++ks) {
+        const int d0 = 16 * ks + 8 * half;
+        qf[ks] = 0;
+        if (d0 < D) qf[ks] = chunk_to_fp8(*reinterpret_cast<const u32x4*>(qrow + d0), scale_log2);
+    }
+
+    // ---- staging state: this thread's chunks of a KT8 x D tile ------------------------------------------------
+    u32x4 rk[C::NCH], rv[C::NCH];
+    int srow[C::NCH], scol[C::NCH];
+#pragma unroll
+    for (int i = 0; i < C::NCH; ++i) {
+        const int idx = tid + i * 256;
+        srow[i] = idx < KT8 * C::CPRD ? idx / C::CPRD : KT8;
+        scol[i] = (idx % C::CPRD) * 8;
+    }
+    auto tile_load = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < C::NCH; ++i)
+            if (srow[i] < KT8 && kv0 + srow[i] < Nk) {
+                rk[i] = *reinterpret_cast<const u32x4*>(kb + (size_t)(kv0 + srow[i]) * ldk + scol[i]);
+                rv[i] = *reinterpret_cast<const u32x4*>(vb + (size_t)(kv0 + srow[i]) * ldk + scol[i]);
+            }
+    };
+    auto tile_store = [&](char* buf, int kv0) {
+        char* kt = buf;
+        char* vt = buf + C::TILEK;
+#pragma unroll
+        for (int i = 0; i < C::NCH; ++i)
+            if (srow[i] < KT8 && kv0 + srow[i] < Nk) {
+                *reinterpret_cast<long*>(kt + srow[i] * C::RSK + scol[i]) = chunk_to_fp8(rk[i], 1.0f);
+                const long v8 = chunk_to_fp8(rv[i], 1.0f);
+                const int kp = vperm(srow[i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vt[(scol[i] + j) * C::RSV + kp] = (char)(v8 >> (8 * j));
+            }
+    };
+
+    // zero both buffers once (padding columns, never-stored rows of a ragged last tile), then the ones row of V^T
+    {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int o = tid * 16; o < C::LDS; o += 256 * 16) *reinterpret_cast<u32x4*>(smem + o) = z;
+        __syncthreads();
+        for (int i = tid; i < 2 * KT8; i += 256) smem[(i / KT8) * C::TILE + C::TILEK + D * C::RSV + (i % KT8)] = 0x38;   // e4m3 1.0
+    }
+
+    f32x16 o[C::NDB];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    constexpr float PSH = 7.0f;                 // P is kept as p * 2^7
+    float m_ref = 0.f;                          // running row max minus PSH (log2 units); meaningful after tile 0
+    const int ntiles = (Nk + KT8 - 1) / KT8;
+    tile_load(0);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        char* buf = smem + (kt & 1) * C::TILE;  // last read in iteration kt-2; every wave has passed a barrier since
+        tile_store(buf, kt * KT8);
+        __syncthreads();
+        if (kt + 1 < ntiles) tile_load((kt + 1) * KT8);
+
+        // ---- S'^T = K Q^T - m_ref for the two 32-row kv blocks
+        f32x16 s[2];
+        const float cinit = -m_ref;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[jb][r] = cinit;
+            const char* krow = buf + (jb * 32 + l31) * C::RSK + half * 8;
+#pragma unroll
+            for (int ks = 0; ks < C::NKS; ++ks) {
+                const long kf = *reinterpret_cast<const long*>(krow + ks * 16);
+                s[jb] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(kf, qf[ks], s[jb], 0, 0, 0);
+            }
+        }
+        if (kt * KT8 + KT8 > Nk) {              // ragged last tile only
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = kt * KT8 + jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (kv >= Nk) s[jb][r] = -INFINITY;
+                }
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[jb][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        if (kt == 0 || !__all(tmax <= PSH)) {
+            const float delta = kt == 0 ? tmax - PSH : fmaxf(tmax - PSH, 0.f);
+            m_ref += delta;
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[jb][r] -= delta;
+            if (kt != 0) {
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+            }
+        }
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[jb][r] = __builtin_amdgcn_exp2f(s[jb][r]);
+
+        // ---- O^T += V^T P^T
+        const char* vt = buf + C::TILEK;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const unsigned plo = pack4_fp8(s[jb][8 * s2 + 0], s[jb][8 * s2 + 1], s[jb][8 * s2 + 2], s[jb][8 * s2 + 3]);
+                const unsigned phi = pack4_fp8(s[jb][8 * s2 + 4], s[jb][8 * s2 + 5], s[jb][8 * s2 + 6], s[jb][8 * s2 + 7]);
+                const long pf = (long)(((unsigned long)phi << 32) | plo);
+                const char* vcol = vt + jb * 32 + 16 * s2 + 8 * half;
+#pragma unroll
+                for (int db = 0; db < C::NDB; ++db) {
+                    const long vf = *reinterpret_cast<const long*>(vcol + (db * 32 + l31) * C::RSV);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pf, o[db], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // row D of O^T = sum(P): block D/32, in-block row D%32 = (r&3)+8(r>>2)+4*half
+    constexpr int RB = D / 32, RR = D % 32;
+    constexpr int RH = (RR >> 2) & 1, REG = (RR & 3) + 4 * (RR >> 3);
+    const float mine = o[RB][REG];
+    const float other = __shfl_xor(mine, 32);
+    const float inv = 1.0f / ((half == RH) ? mine : other);
+    if (q < p.Nq) {
+        bf16* orow = (bf16*)p.out + ((size_t)b * p.Nq + q) * p.ldo + h * D;
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = db * 32 + 8 * g + 4 * half;
+                if (d < D) {
+                    bf16x4 v4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v4[j] = (bf16)(o[db][4 * g + j] * inv);
+                    *reinterpret_cast<bf16x4*>(orow + d) = v4;
+                }
+            }
+    }
+}
+
+template <int D>
+int launch_f8(const AttnArgs& a, hipStream_t s) {
+    typedef F8Cfg<D> C;
+    static bool attr_done = false;
+    auto kern = attn_fp8_kernel<D>;
+    if (!attr_done) {
+        DSIM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
+        attr_done = true;
+    }
+    const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+    hipLaunchKernelGGL(kern, dim3(((a.Nq + 127) / 128) * a.H * a.B), dim3(256), C::LDS, s, a, sl2);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+
+}  // namespace
+
+// bf16 q/k/v in, bf16 out; head dims of the DiT graphs: 72 (DiT-XL/2), 32 (test config)
+int launch_attention_fp8(const AttnArgs& a, hipStream_t s) {
+    if (!a.q || !a.k || !a.v || !a.out || a.B < 1 || a.Bkv < 1 || a.H < 1 || a.Nq < 1 || a.Nk < 1) return DSIM_ERR_INVALID;
+    if (a.ldq % 8 || a.ldk % 8 || a.ldo % 4) return DSIM_ERR_INVALID;
+    if (a.D == 72) return launch_f8<72>(a, s);
+    if (a.D == 32) return launch_f8<32>(a, s);
+    return DSIM_ERR_INVALID;
+}
+
+}  // namespace dsim

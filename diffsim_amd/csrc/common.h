@@ -109,6 +109,7 @@ struct AttnArgs {
     int xcd_remap = 1;                        // 0: plain block order (micro-benchmark A/B only)
 };
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
+int launch_attention_fp8(const AttnArgs& a, hipStream_t s);      // bf16 in/out, e4m3 MFMAs (attention_fp8.hip)
 size_t pair_score_scratch_bytes(int n_pairs, int B, int H, int N, int D);
 int launch_pair_score(const void* q, const void* k, const void* v, const int32_t* idx_a,
                       const int32_t* idx_b, int n_pairs, int B, int H, int N, int D, int dtype,

@@ -26,6 +26,7 @@ struct dsim_dit : WeightStore {
     float* mod = nullptr;       // [depth][6][2][D]  shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     float* scratch = nullptr;   // freq[freq_dim] + h1[D] + temb[D] + m6[6D]
     bool cond_set = false;
+    int attn_mode = 0;          // 0: compute dtype, 1: fp8 e4m3 MFMAs (dsim_dit_set_attention)
 };
 
 namespace {
@@ -150,7 +151,8 @@ struct DWalk {
                 a.q = big; a.ldq = 3 * D;
                 a.k = (char*)big + (size_t)D * es(); a.v = (char*)big + (size_t)2 * D * es(); a.ldk = 3 * D;
                 a.out = ab; a.ldo = D; a.B = n * 2; a.Bkv = n * 2; a.H = H; a.Nq = T; a.Nk = T; a.D = D / H;
-                CK(launch_attention(a, h->dt, s));
+                if (h->attn_mode == 1) CK(launch_attention_fp8(a, s));
+                else CK(launch_attention(a, h->dt, s));
             }
             CK(linear(ab, D, ow->p, (const float*)ob->p, x, M, D, 0, modv(blk, 2), x, T));
             if (run) CK(launch_layernorm_mod(x, modv(blk, 4), modv(blk, 3), nb, M, D, T, 1e-6f, h->dt, s));
@@ -250,6 +252,14 @@ int dsim_dit_set_conditioning(dsim_dit* h, int t_model, int y0, int y1, void* st
     }
     DSIM_HIP_CHECK(hipGetLastError());
     h->cond_set = true;
+    return DSIM_OK;
+}
+
+int dsim_dit_set_attention(dsim_dit* h, int mode) {
+    if (!h || (mode != 0 && mode != 1)) return DSIM_ERR_INVALID;
+    const int hd = h->cfg.num_heads > 0 ? h->cfg.hidden_size / h->cfg.num_heads : 0;
+    if (mode == 1 && (h->dt != DSIM_BF16 || (hd != 72 && hd != 32))) return DSIM_ERR_INVALID;
+    h->attn_mode = mode;
     return DSIM_OK;
 }
 

@@ -716,4 +716,15 @@ int dsim_op_attention(const void* q, int ldq, const void* k, const void* v, int 
     return DSIM_OK;
 }
 
+int dsim_op_attention_fp8(const void* q, int ldq, const void* k, const void* v, int ldk, void* out, int ldo, int B, int Bkv,
+                          int H, int Nq, int Nk, int D, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    AttnArgs a;
+    a.q = q; a.ldq = ldq; a.k = k; a.v = v; a.ldk = ldk; a.out = out; a.ldo = ldo;
+    a.B = B; a.Bkv = Bkv; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D;
+    CK(launch_attention_fp8(a, s));
+    DSIM_HIP_CHECK(hipStreamSynchronize(s));
+    return DSIM_OK;
+}
+
 }  // extern "C"

@@ -19,7 +19,8 @@ from .image import load_image, process_image
 
 class diffsim_DiT:
     def __init__(self, img_size=256, target_step=600, device="cuda", ckpt=None, *, dit_config: DiTConfig = DIT_XL2,
-                 state_dict: Optional[Dict[str, torch.Tensor]] = None, vae=None, torch_dtype=torch.bfloat16):
+                 state_dict: Optional[Dict[str, torch.Tensor]] = None, vae=None, torch_dtype=torch.bfloat16,
+                 fp8_attention: bool = False):
         if state_dict is None:
             raise ValueError("state_dict (DiT weights under DiT/modelsdit.py keys) is required; no checkpoint is bundled")
         if img_size // 8 != dit_config.input_size:
@@ -27,11 +28,14 @@ class diffsim_DiT:
         self.cfg, self.state_dict, self.vae = dit_config, state_dict, vae
         self.dtype = torch.bfloat16 if torch_dtype == torch.float16 else torch_dtype
         self.device = torch.device("cuda:0" if device == "cuda" else device)
+        self.fp8_attention = fp8_attention      # e4m3 MFMAs for QK^T and PV inside the DiT blocks (opt-in)
         self._engines: Dict[int, DiTEngine] = {}
 
     def engine(self, layer: int) -> DiTEngine:
         if layer not in self._engines:
             self._engines[layer] = DiTEngine(self.cfg, self.state_dict, self.dtype, layer, str(self.device))
+            if self.fp8_attention:
+                self._engines[layer].set_attention(True)
         return self._engines[layer]
 
     def prepare_image_latents(self, image, generator=None):

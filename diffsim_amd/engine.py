@@ -321,13 +321,19 @@ def op_layernorm(x, gamma, beta, eps=1e-5):
     return out
 
 
-def op_attention(q, k, v, heads):
-    """q: [B][Nq][H*D]; k,v: [Bkv][Nk][H*D] -> [B][Nq][H*D]."""
+def op_attention(q, k, v, heads, fp8: bool = False):
+    """q: [B][Nq][H*D]; k,v: [Bkv][Nk][H*D] -> [B][Nq][H*D].  fp8: bf16 tensors, e4m3 MFMAs (DiT config 5)."""
     L = _lib.lib()
     _require_cuda(q, k, v)
     B, Nq, HD = q.shape
     Bkv, Nk, _ = k.shape
     out = torch.empty_like(q)
+    if fp8:
+        if q.dtype != torch.bfloat16:
+            raise _lib.DsimError("fp8 attention takes bf16 tensors")
+        _lib.check(L.dsim_op_attention_fp8(q.data_ptr(), HD, k.data_ptr(), v.data_ptr(), HD, out.data_ptr(), HD, B, Bkv, heads,
+                                           Nq, Nk, HD // heads, _stream_ptr()), "op_attention_fp8")
+        return out
     _lib.check(L.dsim_op_attention(q.data_ptr(), HD, k.data_ptr(), v.data_ptr(), HD, out.data_ptr(), HD, B, Bkv, heads,
                                    Nq, Nk, HD // heads, _TORCH2DSIM[q.dtype], _stream_ptr()), "op_attention")
     return out
@@ -469,6 +475,10 @@ class DiTEngine:
             del keep
         self._ws = None
         self._cond = None
+
+    def set_attention(self, fp8: bool):
+        """fp8 (OCP e4m3) MFMA attention in the DiT blocks (BASELINE config 5); bf16 handles only."""
+        _lib.check(self.L.dsim_dit_set_attention(self._h, 1 if fp8 else 0), "dsim_dit_set_attention")
 
     def __del__(self):
         try:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DSIM_ABI_VERSION 2
+#define DSIM_ABI_VERSION 3
 
 typedef enum dsim_status {
     DSIM_OK = 0,
@@ -205,6 +205,11 @@ int    dsim_dit_finalize(dsim_dit* h, void* stream);
 /* t_model = the timestep the MODEL sees = SpacedDiffusion.timestep_map[1000 - target_step]
  * (DiT/diffusion/respace.py:117-129); y0,y1 = class labels of the two batch halves (1 and num_classes = null) */
 int    dsim_dit_set_conditioning(dsim_dit* h, int t_model, int y0, int y1, void* stream);
+/* Attention arithmetic of the DiT blocks: 0 = the handle's compute dtype (default), 1 = fp8 (OCP e4m3) MFMAs for
+ * both QK^T and PV with f32 softmax (BASELINE.json config 5; bf16 handles, head_dim 72 or 32 only).  The
+ * reference's timm Attention (DiT/modelsdit.py:103-124, F.scaled_dot_product_attention in fp16) has no such mode:
+ * it is an opt-in accuracy/throughput trade, compared with the oracle under a stated looser tolerance. */
+int    dsim_dit_set_attention(dsim_dit* h, int mode);
 size_t dsim_dit_workspace_bytes(const dsim_dit* h, int n_images);
 /* x_t = sqrt_abar*latents + sqrt_1m_abar*noise (DDIM add_noise at t = target_step, diffsim_dit.py:63-72);
  * q,k,v (out): compute dtype [n_images][2][tokens][heads*head_dim] */
@@ -228,6 +233,9 @@ int dsim_op_layernorm(const void* x, const float* gamma, const float* beta, void
 int dsim_op_attention(const void* q, int ldq, const void* k, const void* v, int ldk, void* out,
                       int ldo, int B, int Bkv, int H, int Nq, int Nk, int D, int dtype,
                       void* stream);
+/* the same attention on bf16 tensors with fp8 (e4m3) MFMAs -- the kernel behind dsim_dit_set_attention(h, 1); D = 72 or 32 */
+int dsim_op_attention_fp8(const void* q, int ldq, const void* k, const void* v, int ldk, void* out,
+                          int ldo, int B, int Bkv, int H, int Nq, int Nk, int D, void* stream);
 
 #ifdef __cplusplus
 }

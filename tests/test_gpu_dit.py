@@ -46,3 +46,34 @@ def test_dit_golden_and_oracle(golden_dir):
         assert (got[0].float().cpu() - r16).abs().max().item() <= 4e-3 * float(r16.abs().max())     # fp16 reference
     with pytest.raises(IndexError):
         dd.score_latent_pairs(zA, zB, nA, nB, 0, 400)                       # 1000-400 outside the 400-entry schedule
+
+
+def test_dit_fp8_attention_mode(golden_dir):
+    """BASELINE config 5: DiT with fp8 (e4m3) MFMA attention in every block below the tap.  Opt-in; compared with the
+    fp32 oracle under a stated fp8-sized tolerance: |score error| <= 3e-2 (the bf16 mode's bound on this config) and
+    q/k/v of the tapped block within 6 % of their range; it must differ from the bf16 mode (i.e. really run fp8)."""
+    from oracle import cpu_ref as R
+    from diffsim_amd import _lib
+    from diffsim_amd.diffsim_dit import diffsim_DiT
+    sd = S.make_state_dict(C.DIT_TINY, seed=0)
+    m = R.DiTOracle(R.DIT_TINY)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    g = np.load(os.path.join(golden_dir, "g9_dit_tiny.npz"))
+    zA, zB, nA, nB = (torch.from_numpy(g[k]) for k in ("latA", "latB", "noiseA", "noiseB"))
+    d8 = diffsim_DiT(128, 600, "cuda", dit_config=C.DIT_TINY, state_dict=sd, torch_dtype=torch.bfloat16, fp8_attention=True)
+    d16 = diffsim_DiT(128, 600, "cuda", dit_config=C.DIT_TINY, state_dict=sd, torch_dtype=torch.bfloat16)
+    for layer, step, sim in ((2, 600, "cosine"), (1, 700, "cosine"), (2, 600, "mse")):
+        so = float(R.diffsim_dit_latents(m, zA, zB, nA, nB, step, layer, sim))
+        s8 = float(d8.score_latent_pairs(zA, zB, nA, nB, layer, step, sim).cpu())
+        s16 = float(d16.score_latent_pairs(zA, zB, nA, nB, layer, step, sim).cpu())
+        assert abs(s8 - so) <= 3e-2 * max(1.0, abs(so)), (layer, step, sim, s8, so)
+        assert s8 != s16
+    q8, k8, v8 = d8.features(zB, nB, 2, 600)
+    qo, ko, vo = R.dit_features(m, zB, nB, 600, 2)
+    for got, want in ((q8, qo), (k8, ko), (v8, vo)):
+        w = want.transpose(1, 2).reshape(2, want.shape[2], -1)
+        assert (got[0].float().cpu() - w).abs().max().item() <= 6e-2 * float(w.abs().max())
+    with pytest.raises(_lib.DsimError):                                      # fp32 handles have no fp8 mode
+        diffsim_DiT(128, 600, "cuda", dit_config=C.DIT_TINY, state_dict=sd, torch_dtype=torch.float32,
+                    fp8_attention=True).score_latent_pairs(zA, zB, nA, nB, 2, 600, "cosine")

@@ -51,11 +51,13 @@ template <typename T, int D> struct ACfg {
     static constexpr int CPR = DPL / VEC;         // 16-B chunks per row
     static constexpr int TILEK = KT * RS;
     static constexpr int TILE = (KT * RS + KT * RSV + 1) / 2;   // average, so that 2*TILE = K tile + V tile
-    static constexpr bool PIPE = sizeof(T) == 2;
+    // double-buffered staging, except for the widest heads: there two tile pairs (83 KB) would leave one workgroup per
+    // CU; a single pair lets a second workgroup hide this one's load latency instead
+    static constexpr bool PIPE = sizeof(T) == 2 && DPL < 160;
     static constexpr int LDS = (PIPE ? 4 : 2) * TILE;
     // waves per SIMD the register budget is held to (occupancy hides the serial MFMA/VALU phases)
     // (4 workgroups per CU need <= 40 KB of LDS each: true for d <= 48 now that the K tile is 48 columns wide)
-    static constexpr int WPS = (sizeof(T) == 2 && DPL <= 64) ? (LDS <= 40 * 1024 ? 4 : 3) : ((sizeof(T) == 2 && DPL <= 96) ? 2 : 1);
+    static constexpr int WPS = (sizeof(T) == 2 && DPL <= 64) ? (LDS <= 40 * 1024 ? 4 : 3) : ((sizeof(T) == 2 && DPL <= 96) ? 2 : (sizeof(T) == 2 ? 2 : 1));
 };
 
 struct FragF32 { f32x4 lo, hi; };

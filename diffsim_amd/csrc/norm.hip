@@ -333,7 +333,7 @@ int ln_typed(const void* x, const float* gamma, const float* beta, void* out, in
     const int S = C / VEC;
     const dim3 block(256);
     if (S <= 64)
-        hipLaunchKernelGGL((layernorm_kernel<T, MOD, 1, 4>), dim3((M + 15) / 16), block, 0, s, (const T*)x, gamma, beta,
+        hipLaunchKernelGGL((layernorm_kernel<T, MOD, 1, 8>), dim3((M + 31) / 32), block, 0, s, (const T*)x, gamma, beta,
                            (T*)out, M, C, eps, rpb);
     else if (S <= 128)
         hipLaunchKernelGGL((layernorm_kernel<T, MOD, 2, 2>), dim3((M + 7) / 8), block, 0, s, (const T*)x, gamma, beta,
@@ -421,10 +421,10 @@ int gn_typed(const void* x0, int C0, const void* x1, int C1, const float* gamma,
     const int chunks = gn_chunks(HW);
     const size_t lds = (size_t)R * C * 2 * sizeof(float);
     if (lds > 64 * 1024) return DSIM_ERR_INVALID;
-    // row blocks per image of the apply pass (no effect on the numbers): about 2048 workgroups in all, so that large
+    // row blocks per image of the apply pass (no effect on the numbers): about 1024 workgroups in all, so that large
     // batches amortise each workgroup's statistics fold over more rows and small batches still fill the chip
     int rb = HW / (R * 4);
-    const int want = (2048 + B - 1) / B;
+    const int want = (1024 + B - 1) / B;
     if (rb > want) rb = want;
     rb = rb < 1 ? 1 : (rb > 64 ? 64 : rb);
     const int ns = (S + tpr - 1) / tpr;

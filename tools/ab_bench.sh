@@ -1,11 +1,14 @@
 #!/bin/bash
-# Development aid: same-box A/B of two builds of libdiffsim_amd.so.  Put the two builds at ab_libs/lib_base.so and
-# ab_libs/lib_nt.so (any variant), then: gpurun -- ./tools/ab_bench.sh
+# Development aid: same-box A/B of several builds of libdiffsim_amd.so.  Put the builds at ab_libs/lib_<name>.so
+# (ab_libs/ is git-ignored but travels with gpurun), then: gpurun -- ./tools/ab_bench.sh [reps]
 R=$(pwd)
-for rep in 1 2; do
-  for v in base nt; do
-    cp $R/ab_libs/lib_$v.so $R/diffsim_amd/libdiffsim_amd.so
+REPS=${1:-2}
+cp $R/diffsim_amd/libdiffsim_amd.so /tmp/lib_orig.so
+for rep in $(seq 1 $REPS); do
+  for f in $R/ab_libs/lib_*.so; do
+    v=$(basename $f .so); v=${v#lib_}
+    cp $f $R/diffsim_amd/libdiffsim_amd.so
     python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'])"
   done
 done
-cp $R/ab_libs/lib_base.so $R/diffsim_amd/libdiffsim_amd.so
+cp /tmp/lib_orig.so $R/diffsim_amd/libdiffsim_amd.so

@@ -32,7 +32,13 @@ void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn) {
     const bool n320 = !geglu && a.N % 320 == 0, n256 = a.N % 256 == 0;
     // 192-wide: the DiT widths (1152, 3456) that neither 320 nor 256 divides; linear layers only
     const bool n192 = !geglu && a.mode == GEMM_LINEAR && !n320 && !n256 && a.N % 192 == 0;
+    // 128-wide: the VAE's 128-channel 3x3 convs at 512 x 512 (N = 128 exactly)
+    const bool n128 = !geglu && a.mode == GEMM_CONV3 && a.N == 128;
     int want256 = 0;
+    if (n128) {
+        const long tiles = (long)((a.M + 255) / 256);
+        if (tiles >= 256 && g_force_bm != 128) { *bm = 256; *bn = 128; return; }
+    }
     if (n320 || n256 || n192) {
         const int bnb = n320 ? 320 : (n256 ? 256 : 192);
         const long tiles = (long)((a.M + 255) / 256) * (a.N / bnb);
@@ -564,9 +570,11 @@ int launch_typed(const GemmArgs& a, hipStream_t s) {
         // bf16, big problems: 256-row tiles, 8 waves as 4(M) x 2(N), 64-row x (BN/2)-column sub-tiles
         if (big) {
             if (a.epi == EPI_GEGLU) return launch_one<T, 256, 256, GEMM_LINEAR, true, 4, 2>(a, s);
-            if (a.mode == GEMM_CONV3)
+            if (a.mode == GEMM_CONV3) {
+                if (bn == 128) return launch_one<T, 256, 128, GEMM_CONV3, false, 4, 2>(a, s);
                 return bn == 320 ? launch_one<T, 256, 320, GEMM_CONV3, false, 4, 2>(a, s)
                                  : launch_one<T, 256, 256, GEMM_CONV3, false, 4, 2>(a, s);
+            }
             if (slow) return bn == 192 ? launch_one<T, 256, 192, GEMM_LINEAR, false, 4, 2, true>(a, s)
                                        : launch_one<T, 256, 256, GEMM_LINEAR, false, 4, 2, true>(a, s);
             if (bn == 192) return launch_one<T, 256, 192, GEMM_LINEAR, false, 4, 2>(a, s);

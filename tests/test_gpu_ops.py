@@ -256,3 +256,19 @@ def test_attention_fp8(eng, B, Bkv, H, Nq, Nk, D):
     assert float(err.mean()) <= 1.5e-2 * scale, (float(err.mean()), scale)
     got16 = eng.op_attention(qd, kd, vd, H).float().cpu()
     assert float((got16 - want).abs().max()) < float(err.max())            # the bf16 kernel is the accurate one
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_vae_width_many_tiles(eng, dtype):
+    """The VAE's 128 -> 128 channel 3x3 conv on a large map (bf16: 256x128 tiles, 320 of them)."""
+    B, H, W, Cin, Cout = 5, 128, 128, 128, 128
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(B, H, W, Cout, generator=g)
+    got = eng.op_conv3x3(_dev(x, dtype), _dev(w), _dev(b), _dev(r, dtype)).float().cpu()
+    sel = [0, 4]
+    want = F.conv2d(_q(x[sel], dtype).permute(0, 3, 1, 2), _q(w, dtype), b, padding=1).permute(0, 2, 3, 1) + _q(r[sel], dtype)
+    _close(got[sel], want, dtype)
+    assert torch.isfinite(got).all()

@@ -31,7 +31,9 @@ template <> struct Vec16<float> { typedef f32x4 type; static constexpr int N = 4
 
 __host__ __device__ inline int gn_chunks(int HW) {
     int c = HW / 64;
-    return c < 1 ? 1 : (c > 32 ? 32 : c);
+    c = c < 1 ? 1 : (c > 32 ? 32 : c);
+    if (HW > 16384) c = 64;          // the VAE's 256^2 / 512^2 maps: few images, so more slabs per image
+    return c;
 }
 
 template <typename T>
@@ -438,7 +440,7 @@ int gn_typed(const void* x0, int C0, const void* x1, int C1, const float* gamma,
 
 }  // namespace
 
-size_t groupnorm_scratch_bytes(int B, int groups) { return (size_t)B * 32 * groups * 2 * sizeof(double); }
+size_t groupnorm_scratch_bytes(int B, int groups) { return (size_t)B * 64 * groups * 2 * sizeof(double); }
 
 int launch_groupnorm(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta,
                      void* out, int B, int HW, int groups, float eps, int silu, int dtype, void* scratch,

@@ -99,7 +99,8 @@ def test_conv3x3(eng, dtype, B, H, W, Cin, Cout, stride, ups):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,HW,C0,C1,silu,eps", [
     (2, 256, 320, 0, True, 1e-5), (3, 64, 1280, 640, True, 1e-5), (2, 4096, 320, 0, False, 1e-6),
-    (2, 16, 256, 128, True, 1e-5), (1, 1, 1280, 1280, True, 1e-5), (2, 1024, 64, 0, True, 1e-5)])
+    (2, 16, 256, 128, True, 1e-5), (1, 1, 1280, 1280, True, 1e-5), (2, 1024, 64, 0, True, 1e-5),
+    (2, 40000, 128, 0, True, 1e-6)])        # a VAE-sized map: 64 statistics slabs per image, ragged slab lengths
 def test_groupnorm(eng, dtype, B, HW, C0, C1, silu, eps):
     g = torch.Generator().manual_seed(HW + C0 + C1)
     C = C0 + C1

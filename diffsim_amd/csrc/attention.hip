@@ -32,6 +32,14 @@
 namespace dsim {
 namespace {
 
+// max over the two 32-lane halves of a wave in every lane: one v_permlane32_swap (gfx950) instead of a ds_bpermute
+// round trip through the LDS pipe -- the softmax branches on this value once per key tile
+__device__ __forceinline__ float max_halves(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // r[0] = lower half, r[1] = upper half, in both
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 constexpr int KT = 64;   // kv rows per LDS tile
 
 template <typename T, int D> struct ACfg {
@@ -251,7 +259,7 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[jb][r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        tmax = max_halves(tmax);
         // tmax is relative to m_run.  Tile 0 always re-bases; later tiles only when some row's max
         // grew (the running max settles after a few tiles) -- exact, not a threshold.
         if (kt == 0 || !__all(tmax <= 0.f)) {

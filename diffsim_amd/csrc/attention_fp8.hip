@@ -19,6 +19,14 @@
 namespace dsim {
 namespace {
 
+// max over the two 32-lane halves of a wave in every lane: one v_permlane32_swap (gfx950) instead of a ds_bpermute
+// round trip through the LDS pipe -- the softmax branches on this value once per key tile
+__device__ __forceinline__ float max_halves(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // r[0] = lower half, r[1] = upper half, in both
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 constexpr int KT8 = 64;                      // kv rows per LDS tile
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void attn_fp8_kernel(const AttnArgs p, cons
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[jb][r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        tmax = max_halves(tmax);
         if (kt == 0 || !__all(tmax <= PSH)) {
             const float delta = kt == 0 ? tmax - PSH : fmaxf(tmax - PSH, 0.f);
             m_ref += delta;

@@ -172,6 +172,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # every rank builds the same synthetic weights on the host: share the cores instead of oversubscribing them
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
         dist.init_process_group("nccl", device_id=dev)
 
     from diffsim_amd.diffsim import DiffSim

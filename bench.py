@@ -332,6 +332,7 @@ def main():
                                    "abs_err": abs(float(scores[0]) - float(so))}
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()                     # rank 0 ran one extra (profiled) step: leave together
         dist.destroy_process_group()
 
 

@@ -273,3 +273,26 @@ def test_conv3x3_vae_width_many_tiles(eng, dtype):
     want = F.conv2d(_q(x[sel], dtype).permute(0, 3, 1, 2), _q(w, dtype), b, padding=1).permute(0, 2, 3, 1) + _q(r[sel], dtype)
     _close(got[sel], want, dtype)
     assert torch.isfinite(got).all()
+
+
+def test_linear_randomized_shapes(eng):
+    """Seeded sweep over ragged M, every supported N/K granularity, bias / residual on and off, both dtypes: the
+    tile / epilogue-kind / persistence choice is data-dependent, so walk many combinations."""
+    rng = np.random.default_rng(7)
+    for case in range(40):
+        dtype = DTYPES[case % 2]
+        M = int(rng.choice([1, 31, 128, 257, 1000, 4097, 20000]))
+        N = int(rng.choice([64, 128, 160, 192, 256, 320, 384, 640, 1152]))
+        K = int(rng.choice([64, 128, 320, 576, 1280]))
+        use_bias, use_res = bool(rng.integers(2)), bool(rng.integers(2))
+        g = torch.Generator().manual_seed(case)
+        x = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / math.sqrt(K)
+        b = torch.randn(N, generator=g) if use_bias else None
+        r = torch.randn(M, N, generator=g) if use_res else None
+        want = F.linear(_q(x, dtype), _q(w, dtype), b) + (_q(r, dtype) if use_res else 0)
+        got = eng.op_linear(_dev(x, dtype), _dev(w), _dev(b) if use_bias else None, _dev(r, dtype) if use_res else None)
+        try:
+            _close(got, want, dtype)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: M={M} N={N} K={K} bias={use_bias} res={use_res} {dtype}: {e}")

@@ -296,3 +296,31 @@ def test_linear_randomized_shapes(eng):
             _close(got, want, dtype)
         except AssertionError as e:
             raise AssertionError(f"case {case}: M={M} N={N} K={K} bias={use_bias} res={use_res} {dtype}: {e}")
+
+
+def test_conv3x3_randomized_shapes(eng):
+    """Seeded sweep over odd map sizes, channel counts, stride 2 and the folded 2x upsample, both dtypes."""
+    rng = np.random.default_rng(11)
+    for case in range(24):
+        dtype = DTYPES[case % 2]
+        B = int(rng.choice([1, 2, 5]))
+        H, W = int(rng.choice([3, 8, 13, 32, 40])), int(rng.choice([4, 8, 17, 32]))
+        Cin, Cout = int(rng.choice([64, 128, 320, 640])), int(rng.choice([64, 128, 160, 320]))
+        mode = int(rng.integers(3))                       # 0 plain, 1 stride 2, 2 upsample
+        if mode == 1 and (H % 2 or W % 2):
+            H, W = H + H % 2, W + W % 2
+        stride, ups = (2, False) if mode == 1 else ((1, True) if mode == 2 else (1, False))
+        g = torch.Generator().manual_seed(100 + case)
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+        b = torch.randn(Cout, generator=g)
+        xin = _q(x, dtype)
+        if ups:
+            xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+        want = F.conv2d(xin, _q(w, dtype), b, stride=stride, padding=1)
+        r = torch.randn(want.shape, generator=g)
+        got = eng.op_conv3x3(_dev(x.permute(0, 2, 3, 1), dtype), _dev(w), _dev(b), _dev(r.permute(0, 2, 3, 1), dtype), stride, ups)
+        try:
+            _close(got.float().cpu().permute(0, 3, 1, 2), want + _q(r, dtype), dtype)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: B={B} H={H} W={W} Cin={Cin} Cout={Cout} stride={stride} ups={ups} {dtype}: {e}")

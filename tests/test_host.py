@@ -147,3 +147,17 @@ def test_bench_kernel_names_match_the_committed_rocprof_summaries():
         assert name in mfma and name in hbm, (fam, name)
     assert line["roofline"]["kernel"] in stats
     assert bench.pmc_traffic(line["roofline"]["kernel"]) and bench.pmc_mfma_util(line["roofline"]["kernel"])
+
+
+def test_public_header_is_plain_c99(tmp_path):
+    """The drop-in boundary is a C ABI: include/diffsim_amd.h must compile as C99 with no C++ or torch types."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "diffsim_amd.h"\nint main(void) { dsim_unet_cfg c; (void)c; return DSIM_ABI_VERSION == 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                        "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

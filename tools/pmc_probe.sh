@@ -3,8 +3,8 @@
 cd /tmp && export TMPDIR=/tmp
 KN=$1; shift
 rm -rf /tmp/p1 /tmp/p2
-timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d /tmp/p1 -- python3 /root/repo/tools/attn_probe.py "$@" > /tmp/o1.log 2>&1
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE --output-format csv -d /tmp/p2 -- python3 /root/repo/tools/attn_probe.py "$@" > /tmp/o2.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d /tmp/p1 -- python3 /root/repo/tools/${PROBE:-attn_probe.py} "$@" > /tmp/o1.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d /tmp/p2 -- python3 /root/repo/tools/${PROBE:-attn_probe.py} "$@" > /tmp/o2.log 2>&1
 python3 - "$KN" <<'PY'
 import csv, glob, collections, sys
 kn = sys.argv[1]

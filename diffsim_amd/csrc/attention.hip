@@ -52,6 +52,10 @@ template <typename T, int D> struct ACfg {
     // K tile: only the NKS*16 columns QK^T reads (bf16); row stride an odd number of 16-B slots (ds_read_b128)
     static constexpr int DPLK = (ES == 2) ? NKS * 16 : DPL;
     static constexpr int RS = DPLK * ES + 16;
+    // bf16, D = 8 (mod 16): K carries a ones column at d = D and Q carries -m there, so S^T comes out of the MFMAs
+    // already relative to the running max and the accumulators start at the constant 0 (no per-tile register fill).
+    // Any per-row reference cancels in the softmax, so -m rounded to bf16 is exact as long as m itself is kept rounded.
+    static constexpr bool KONE = (ES == 2) && (D % 16 == 8);
     // V tile row stride.  bf16: the transposed reads (ds_read_b64_tr_b16) take, per 32-lane half, a
     // 4-row x 32-column block = 4 rows x 16 dwords; they are conflict-free when the row stride is
     // 16 or 48 dwords mod 64 (four rows tile the 64 banks).  f32: plain ds_read_b32, same as K.
@@ -161,6 +165,8 @@ __device__ __forceinline__ void tile_init(StageRegs<T, D>& sr, char* lds, int ld
         for (int i = tid; i < KT * NBUF; i += 256) {
             const int buf = i / KT, r = i - buf * KT;
             *reinterpret_cast<u32x4*>(lds + buf * 2 * C::TILE + C::TILEK + r * C::RSV + (D / C::VEC) * 16) = one_chunk<T>();
+            if constexpr (C::KONE)
+                *reinterpret_cast<u32x4*>(lds + buf * 2 * C::TILE + r * C::RS + (D / C::VEC) * 16) = one_chunk<T>();
         }
     }
 }
@@ -198,14 +204,15 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
                                        OAcc<T, D>& oacc) {
     typedef ACfg<T, D> C;
     typedef typename FragOf<T>::type Frag;
-    const auto& qf = qfr.f;
+    QFrags<T, D> qloc = qfr;    // (KONE writes -m into the spare d = D slot of its own copy)
+    auto& qf = qloc.f;
     auto& o = oacc.b;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    float m_run = 0.f;          // running row max (log2 units); meaningful after tile 0
+    float m_run = 0.f;          // running row max (log2 units); meaningful after tile 0 (KONE: a bf16 value)
     float l_run = 0.f;          // used only when !ONES
 
     const int ntiles = (Nk + KT - 1) / KT;
@@ -231,7 +238,7 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
 
         // ---- S'^T = K Q^T - m for the two 32-row kv blocks (accumulators start at -m) ----------
         f32x16 s[2];
-        const float cinit = -m_run;
+        const float cinit = C::KONE ? 0.f : -m_run;
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
 #pragma unroll
@@ -262,9 +269,21 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
         tmax = max_halves(tmax);
         // tmax is relative to m_run.  Tile 0 always re-bases; later tiles only when some row's max
         // grew (the running max settles after a few tiles) -- exact, not a threshold.
-        if (kt == 0 || !__all(tmax <= 0.f)) {
-            const float delta = kt == 0 ? tmax : fmaxf(tmax, 0.f);
-            m_run += delta;
+        // (KONE re-bases only past a slack of 0.5, so that rounding m to bf16 cannot leave a row just above 0 and
+        // re-trigger on every tile; P <= 1.42 there)
+        constexpr float SLACK = C::KONE ? 0.5f : 0.f;
+        if (kt == 0 || !__all(tmax <= SLACK)) {
+            float delta = kt == 0 ? tmax : fmaxf(tmax, 0.f);
+            if constexpr (C::KONE) {
+                if constexpr (sizeof(T) == 2) {
+                    const float m_new = (float)(bf16)(m_run + delta);      // the value Q can carry exactly
+                    delta = m_new - m_run;
+                    m_run = m_new;
+                    if (half == 1) qf[C::NKS - 1][0] = (bf16)(-m_new);       // d = D lives in element 0 of the upper half
+                }
+            } else {
+                m_run += delta;
+            }
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb)
 #pragma unroll

@@ -20,6 +20,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional, Sequence, Tuple, Union
 
+from concurrent.futures import ThreadPoolExecutor
+
 import torch
 
 from . import scheduler as sched
@@ -71,6 +73,7 @@ class DiffSim:
         self.use_graphs = use_graphs            # replay each U-Net forward as one hipGraph (small, launch-bound batches)
         self._engines: Dict[Tuple[str, int], UNetEngine] = {}
         self._ctx: Dict[str, torch.Tensor] = {}
+        self._pool = ThreadPoolExecutor(max_workers=2)      # host-side image decode / resize
 
     # ------------------------------------------------------------------------------------------
     def engine(self, target_block: str, target_layer: int) -> UNetEngine:
@@ -96,9 +99,25 @@ class DiffSim:
         vae = vae or self.vae
         if vae is None:
             raise RuntimeError("no VAE plugged in: use the latents-in entry points (diffsim_latents / score_latent_pairs)")
+        if isinstance(getattr(vae, "device", None), torch.device):
+            image = image.to(vae.device)          # cast on the device: the same RNE rounding, without 4 ms of host time
         image = image.to(dtype=self.vae_dtype)
         lat = vae.encode(image).latent_dist.sample(generator=generator)
         return vae.config.scaling_factor * lat
+
+    def _pair_latents(self, tensor_A, tensor_B, generator):
+        """Latents of both images.  With the HIP VAE encoder the two images go through ONE encode (its kernels are
+        batch-invariant bit for bit) and are then sampled in the reference's order -- A's draw, then B's."""
+        vae = self.vae
+        if vae is not None and hasattr(vae, "moments") and tensor_A.shape == tensor_B.shape:
+            from .engine import _LatentDist
+            x = torch.cat([tensor_A, tensor_B]).to(vae.device).to(dtype=self.vae_dtype)
+            mom = vae.moments(x)
+            sf = vae.config.scaling_factor
+            return (sf * _LatentDist(mom[0:1]).sample(generator=generator),
+                    sf * _LatentDist(mom[1:2]).sample(generator=generator))
+        return (self.prepare_image_latents(tensor_A, vae, None, generator),
+                self.prepare_image_latents(tensor_B, vae, None, generator))
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -147,11 +166,12 @@ class DiffSim:
         if ip_adapter:
             raise NotImplementedError("IP-Adapter mode is out of scope")
         target_layer = _norm_layer(target_layer)
-        A, B = load_image(image_A), load_image(image_B)
-        tensor_A, tensor_B = process_image(A, img_size), process_image(B, img_size)
+        # decode + Lanczos resize of the two images on two host threads (PIL releases the GIL); same tensors as serially
+        fa = self._pool.submit(lambda: process_image(load_image(image_A), img_size))
+        tensor_B = process_image(load_image(image_B), img_size)
+        tensor_A = fa.result()
         generator = get_generator(seed, "cpu")                   # reference CPU path: CPU generator
-        latentsA = self.prepare_image_latents(tensor_A, self.vae, device, generator)
-        latentsB = self.prepare_image_latents(tensor_B, self.vae, device, generator)
+        latentsA, latentsB = self._pair_latents(tensor_A, tensor_B, generator)
         # DiffSimPipeline.step draws the noise right after prepare_latents: A's step first, then B's
         noiseA = torch.randn(latentsA.shape, generator=generator, dtype=torch.float32)
         noiseB = torch.randn(latentsB.shape, generator=generator, dtype=torch.float32)

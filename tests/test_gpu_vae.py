@@ -63,3 +63,30 @@ def test_vae_sampling_order_and_pixels_in_score(golden_dir):
     nA, nB = torch.randn(zA.shape, generator=g), torch.randn(zB.shape, generator=g)
     so = R.diffsim_latents(ounet, zA, zB, nA, nB, ctx)
     assert abs(float(s.cpu()) - float(so)) <= 1e-4 * abs(float(so)), (float(s.cpu()), float(so))
+
+
+def test_pair_path_equals_two_single_encodes(golden_dir):
+    """diffsim() sends both images through ONE VAE encode, casts on the device and decodes on two host threads:
+    the latents and the score must equal the reference-shaped sequential path (two prepare_image_latents calls)
+    bit for bit."""
+    from diffsim_amd.diffsim import DiffSim, get_generator
+    from diffsim_amd.engine import VAEEncoder
+    from diffsim_amd.image import load_image, process_image
+    vsd = S.make_state_dict(C.VAE_TINY, seed=3)
+    usd = S.make_state_dict(C.TINY, seed=0)
+    ctx = S.make_context(C.TINY)
+    for dtype in (torch.float32, torch.bfloat16):
+        vae = VAEEncoder(C.VAE_TINY, vsd, dtype)
+        ds = DiffSim(torch_dtype=dtype, device="cuda", unet_config=C.TINY, state_dict=usd, vae=vae, encode_prompt=lambda p: ctx)
+        img_a, img_b = os.path.join(golden_dir, "g1_img_c.png"), os.path.join(golden_dir, "g1_img_d.png")
+        s = ds.diffsim(img_a, img_b, 128, "a cat", "up_blocks", [0], 600, seed=2334, similarity="cosine")
+        g = get_generator(2334, "cpu")
+        tA, tB = process_image(load_image(img_a), 128), process_image(load_image(img_b), 128)
+        zA = ds.prepare_image_latents(tA.to(torch.float16), vae, None, g)          # host-side cast, one image per encode
+        zB = ds.prepare_image_latents(tB.to(torch.float16), vae, None, g)
+        g2 = get_generator(2334, "cpu")
+        pA, pB = ds._pair_latents(tA, tB, g2)
+        assert torch.equal(pA, zA) and torch.equal(pB, zB)
+        nA, nB = torch.randn(zA.shape, generator=g), torch.randn(zB.shape, generator=g)
+        s2 = ds.score_latent_pairs(zA.float(), zB.float(), nA, nB, "a cat", "up_blocks", 0, 600, "cosine")
+        assert torch.equal(s, s2)

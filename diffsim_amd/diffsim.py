@@ -73,7 +73,7 @@ class DiffSim:
         self.use_graphs = use_graphs            # replay each U-Net forward as one hipGraph (small, launch-bound batches)
         self._engines: Dict[Tuple[str, int], UNetEngine] = {}
         self._ctx: Dict[str, torch.Tensor] = {}
-        self._pool = ThreadPoolExecutor(max_workers=2)      # host-side image decode / resize
+        self._pool = ThreadPoolExecutor(max_workers=8)      # host-side image decode / resize
 
     # ------------------------------------------------------------------------------------------
     def engine(self, target_block: str, target_layer: int) -> UNetEngine:
@@ -185,6 +185,31 @@ class DiffSim:
         target_layer = _norm_layer(target_layer)
         lA, lB = [], []
         nA = nB = None
+        vae = self.vae
+        if vae is not None and hasattr(vae, "moments"):
+            # HIP VAE: images decoded on the host thread pool, one encode per chunk of pairs; every pair reseeds the
+            # same generator, so its four draws (vaeA, vaeB, noiseA, noiseB) are the same tensors for all pairs
+            from .engine import _LatentDist
+            g = get_generator(seed, "cpu")
+            eps = None
+            sf = vae.config.scaling_factor
+            for i0 in range(0, len(pairs), batch_pairs):
+                chunk = pairs[i0:i0 + batch_pairs]
+                paths = [p for ab in chunk for p in ab]
+                ims = list(self._pool.map(lambda p_: process_image(load_image(p_), img_size), paths))
+                x = torch.cat(ims).to(vae.device).to(dtype=self.vae_dtype)
+                d = _LatentDist(vae.moments(x))
+                if eps is None:
+                    shp = (1,) + tuple(d.mean.shape[1:])
+                    eA = torch.randn(shp, generator=g, dtype=torch.float32).to(vae.device)
+                    eB = torch.randn(shp, generator=g, dtype=torch.float32).to(vae.device)
+                    nA = torch.randn(shp, generator=g, dtype=torch.float32)
+                    nB = torch.randn(shp, generator=g, dtype=torch.float32)
+                    eps = (eA, eB)
+                lA.append((sf * (d.mean[0::2] + d.std[0::2] * eps[0])).float())
+                lB.append((sf * (d.mean[1::2] + d.std[1::2] * eps[1])).float())
+            return self.score_latent_pairs(torch.cat(lA), torch.cat(lB), nA, nB, prompt, target_block, target_layer,
+                                           target_step, similarity, batch_pairs)
         for pa, pb in pairs:
             generator = get_generator(seed, "cpu")
             a = self.prepare_image_latents(process_image(load_image(pa), img_size), self.vae, None, generator)

@@ -90,3 +90,8 @@ def test_pair_path_equals_two_single_encodes(golden_dir):
         nA, nB = torch.randn(zA.shape, generator=g), torch.randn(zB.shape, generator=g)
         s2 = ds.score_latent_pairs(zA.float(), zB.float(), nA, nB, "a cat", "up_blocks", 0, 600, "cosine")
         assert torch.equal(s, s2)
+        # the batched path-based entry point: chunked VAE encodes, same scores as one diffsim() call per pair
+        sr = ds.diffsim(img_b, img_a, 128, "a cat", "up_blocks", [0], 600, seed=2334, similarity="cosine")
+        sp = ds.score_pairs([(img_a, img_b), (img_b, img_a), (img_a, img_b)], 128, "a cat", "up_blocks", [0], 600, seed=2334,
+                            batch_pairs=2)
+        assert torch.equal(sp[0:1], s) and torch.equal(sp[1:2], sr) and torch.equal(sp[2:3], s)

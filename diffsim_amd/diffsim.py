@@ -73,7 +73,7 @@ class DiffSim:
         self.use_graphs = use_graphs            # replay each U-Net forward as one hipGraph (small, launch-bound batches)
         self._engines: Dict[Tuple[str, int], UNetEngine] = {}
         self._ctx: Dict[str, torch.Tensor] = {}
-        self._pool = ThreadPoolExecutor(max_workers=8)      # host-side image decode / resize
+        self._pool = ThreadPoolExecutor(max_workers=16)     # host-side image decode / resize
 
     # ------------------------------------------------------------------------------------------
     def engine(self, target_block: str, target_layer: int) -> UNetEngine:
@@ -193,10 +193,15 @@ class DiffSim:
             g = get_generator(seed, "cpu")
             eps = None
             sf = vae.config.scaling_factor
-            for i0 in range(0, len(pairs), batch_pairs):
-                chunk = pairs[i0:i0 + batch_pairs]
-                paths = [p for ab in chunk for p in ab]
-                ims = list(self._pool.map(lambda p_: process_image(load_image(p_), img_size), paths))
+            def submit(i0):
+                paths = [p for ab in pairs[i0:i0 + batch_pairs] for p in ab]
+                return [self._pool.submit(lambda p_=p_: process_image(load_image(p_), img_size)) for p_ in paths]
+            starts = list(range(0, len(pairs), batch_pairs))
+            pending = [submit(i0) for i0 in starts[:2]]          # decode runs two chunks ahead of the GPU
+            for ci, i0 in enumerate(starts):
+                ims = [f.result() for f in pending.pop(0)]
+                if ci + 2 < len(starts):
+                    pending.append(submit(starts[ci + 2]))
                 x = torch.cat(ims).to(vae.device).to(dtype=self.vae_dtype)
                 d = _LatentDist(vae.moments(x))
                 if eps is None:

@@ -98,9 +98,35 @@ def nights_eval(scorer: DiffSim, image_path: str, img_size: int, target_block, t
     for j in mine:
         by_prompt.setdefault(rows[j]["prompt"], []).append(j)
     order, nA, nB = [], None, None
+    vae = getattr(scorer, "vae", None)
+    fast = vae is not None and hasattr(vae, "moments")        # HIP VAE: chunked encodes, threaded image decode
+    eps = None
     for prompt, idxs in by_prompt.items():
         ref, left, right = [], [], []
-        for j in idxs:
+        if fast:
+            # every call reseeds the same generator: its draws (vae ref, vae other, noise ref, noise other) are the same
+            # tensors for every triplet and for both (ref,left) and (ref,right)
+            from .engine import _LatentDist
+            if eps is None:
+                g = get_generator(seed, "cpu")
+                shp = None
+            sf = vae.config.scaling_factor
+            for c0 in range(0, len(idxs), batch_triplets):
+                chunk = idxs[c0:c0 + batch_triplets]
+                paths = [rows[j][k] for j in chunk for k in ("ref", "left", "right")]
+                ims = list(scorer._pool.map(lambda p_: process_image(load_image(p_), img_size), paths))
+                d = _LatentDist(vae.moments(torch.cat(ims).to(vae.device).to(dtype=scorer.vae_dtype)))
+                if eps is None:
+                    shp = (1,) + tuple(d.mean.shape[1:])
+                    eA = torch.randn(shp, generator=g, dtype=torch.float32).to(vae.device)
+                    eB = torch.randn(shp, generator=g, dtype=torch.float32).to(vae.device)
+                    nA = torch.randn(shp, generator=g, dtype=torch.float32)
+                    nB = torch.randn(shp, generator=g, dtype=torch.float32)
+                    eps = (eA, eB)
+                ref.append((sf * (d.mean[0::3] + d.std[0::3] * eps[0])).float())
+                left.append((sf * (d.mean[1::3] + d.std[1::3] * eps[1])).float())
+                right.append((sf * (d.mean[2::3] + d.std[2::3] * eps[1])).float())
+        for j in ([] if fast else idxs):
             # one generator per (ref,left) call; (ref,right) reproduces the same ref/noise draws
             g = get_generator(seed, "cpu")
             a = scorer.prepare_image_latents(process_image(load_image(rows[j]["ref"]), img_size), None, None, g)

@@ -220,6 +220,17 @@ def test_triplet_harness_matches_pairwise_calls(tiny_env, golden_dir, tmp_path):
             pred = (1 if ab < ac else 0) if sim == "mse" else (1 if ab > ac else 0)
             correct += int(pred == r["vote"])
         assert abs(acc - 100.0 * correct / len(parsed)) < 1e-3
+    # the same run with the HIP VAE encoder (chunked encodes, threaded decode): same rule, same accuracy as pairwise calls
+    from diffsim_amd.engine import VAEEncoder
+    dv = _scorer(C.TINY, tiny_env["sd"], torch.float32, vae=VAEEncoder(C.VAE_TINY, S.make_state_dict(C.VAE_TINY, seed=3), torch.float32),
+                 encode_prompt=lambda p: ctx)
+    acc = Hn.nights_eval(dv, str(tmp_path), 128, "up_blocks", [0], 600, seed=2334, similarity="cosine", batch_triplets=2)
+    correct = 0
+    for r in parsed:
+        ab = dv.diffsim(r["ref"], r["left"], 128, r["prompt"], "up_blocks", [0], 600, seed=2334, similarity="cosine")
+        ac = dv.diffsim(r["ref"], r["right"], 128, r["prompt"], "up_blocks", [0], 600, seed=2334, similarity="cosine")
+        correct += int((1 if ab > ac else 0) == r["vote"])
+    assert abs(acc - 100.0 * correct / len(parsed)) < 1e-3
     # bit-exact equality of cached-reference scores with the pairwise path
     lat = [S.make_pair_latents(C.TINY, i) for i in range(3)]
     ref = torch.cat([p[0] for p in lat]); left = torch.cat([p[1] for p in lat]); right = torch.cat([p[0] for p in lat[::-1]])

@@ -114,14 +114,29 @@ def secondary(a, world, rank, dev):
                (", fp8 (e4m3) MFMA attention" if a.fp8_attention else "")
     zA, zB = zA.to(dev), zB.to(dev)
     n = [t.to(dev) for t in n]
+    scores = run()
     for _ in range(a.warmup):
         scores = run()
+    import torch.distributed as dist
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         scores = run()
+    if world > 1:
+        allscores = [torch.empty_like(scores) for _ in range(world)]
+        dist.all_gather(allscores, scores)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
     extra = {}
     if rank == 0 and a.model == "sdxl" and not a.no_profile:
         # algorithmic FLOPs of the path actually launched (per-launch records of one profiled step)
@@ -145,6 +160,89 @@ def secondary(a, world, rank, dev):
                           "score_sample": [round(float(x), 6) for x in scores[:4].float().cpu()]}), flush=True)
 
 
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_sd15(cfg, sd, lats, noise, gpu_scores, n_pairs):
+    """CPU baseline (rank 0, N=1 only): the oracle (fp32 torch CPU restatement of the reference path) on the host
+    cores over the first `n_pairs` pairs of the batch -- BASELINE config[0] is 4 pairs -- one pair per call as the
+    reference's batch-of-one loop runs (cute_main.py:111-132), U-Net truncated at the tap; then ONE pair in the
+    schedule the reference itself executes (full U-Net to conv_out, diffsim_pipeline.py:213-221: same score, about
+    twice the work).  Also the parity check of those pairs against the HIP scores."""
+    from oracle import cpu_ref as R
+    full = dict(sd)
+    for k_, shp in C.unet_param_shapes(cfg).items():
+        if k_ not in full:
+            full[k_] = torch.zeros(shp)
+    unet = R.build_unet(R.SD15, full)
+    ctx = S.make_context(cfg)
+    n_pairs = max(1, min(n_pairs, len(lats)))
+    cpu_scores = []
+    tc = time.perf_counter()
+    for i in range(n_pairs):
+        zA, zB = lats[i]
+        cpu_scores.append(float(R.diffsim_latents(unet, zA, zB, noise[2], noise[3], ctx, 600, "up_blocks", 0, "cosine")))
+    cpu_s = time.perf_counter() - tc
+    tc = time.perf_counter()
+    so_full = R.diffsim_latents(unet, lats[0][0], lats[0][1], noise[2], noise[3], ctx, 600, "up_blocks", 0, "cosine", full=True)
+    cpu_full_s = time.perf_counter() - tc
+    g = [float(x) for x in gpu_scores[:n_pairs].float().cpu()]
+    errs = [abs(a_ - b_) for a_, b_ in zip(g, cpu_scores)]
+    return {
+        "cpu_baseline": {"value": round(n_pairs / cpu_s, 5), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+                         "sample": "%d pairs (the first pairs of the batch; BASELINE config[0] = 4 pairs), one pair per call, fp32 "
+                                   "torch CPU oracle, U-Net truncated at the tap, %.1f s of CPU work" % (n_pairs, cpu_s),
+                         "cpu_model": cpu_model(), "host_cpu_count": os.cpu_count(),
+                         "reference_schedule_value": round(1.0 / cpu_full_s, 5),
+                         "reference_schedule": "pair 0, full U-Net to conv_out as diffsim_pipeline.py:213 runs it "
+                                               "(score %.6f, %.1f s)" % (float(so_full), cpu_full_s)},
+        "parity_vs_cpu_oracle": {"gpu": [round(x, 6) for x in g], "cpu_oracle": [round(x, 6) for x in cpu_scores],
+                                 "max_abs_err": max(errs)},
+    }
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a torch.distributed launcher around it: start N fresh rank processes
+    (one per GPU) and relay their output; rank 0 prints the JSON line.  The parent never touches the GPU."""
+    from diffsim_amd.parallel import spawn_ranks
+    return spawn_ranks(n, [sys.executable, os.path.abspath(__file__)] + list(argv))
+
+
+def selftest_launch(a, world, rank):
+    """CPU stand-in for the N-rank plumbing (tests/test_bench_launcher.py): gloo process group, the same barrier /
+    max-over-ranks timing / score all_gather / rank census as the GPU path, no kernels."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    el = 1e-3 * (rank + 1)
+    seen = 1
+    scores = torch.full((a.batch_pairs,), float(rank))
+    gathered = [scores]
+    if world > 1:
+        dist.barrier()
+        gathered = [torch.empty_like(scores) for _ in range(world)]
+        dist.all_gather(gathered, scores)
+        tt = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+        c = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(c)
+        seen = int(c.item())
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "n_ranks_seen": seen, "steps": a.steps, "warmup": a.warmup,
+                          "max_rank_s": el, "ranks_in_gather": [int(g[0]) for g in gathered]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,7 +250,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch-pairs", type=int, default=32, help="pairs per step per GPU")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--resident-batches", type=int, default=4,
+                    help="distinct synthetic batches kept in HBM; the timed steps cycle through them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=4, help="pairs the CPU baseline leg scores (config[0] has 4)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--model", choices=["sd15", "sdxl", "dit"], default="sd15",
                     help="sd15 = the headline metric (BASELINE config[1]); sdxl / dit = secondary lines for configs[3], [4]")
@@ -160,13 +261,28 @@ def main():
     ap.add_argument("--pixels-in", action="store_true",
                     help="secondary line: include the VAE encoder (512x512 pixels in HBM -> score); the headline "
                          "metric is latents-in")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="CPU-only check of the N-rank launch + gloo plumbing (no kernels, no throughput)")
     a = ap.parse_args()
 
+    # ---- N ranks: either a torch.distributed launcher started us (WORLD_SIZE set), or we start them ourselves -----
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        if not a.selftest_launch and torch.cuda.device_count() < a.gpus:      # device_count() does not initialise HIP
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but only {torch.cuda.device_count()} GPU(s) visible")
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a mislabelled run")
+    if a.selftest_launch:
+        return selftest_launch(a, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the DiffSim engine has no CPU path")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local}, only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -191,11 +307,13 @@ def main():
     eng.set_timestep(t)
     sa, sb = sched.noise_coefficients(t)
 
-    # ---- one batch of synthetic pairs for this rank, resident in HBM ---------------------------
+    # ---- NB distinct batches of synthetic pairs for this rank, resident in HBM; step i scores batch i % NB --------
     bp = a.batch_pairs
-    lats = [S.make_pair_latents(cfg, rank * bp + i) for i in range(bp)]
+    NB = max(1, a.resident_batches)
+    lats = [S.make_pair_latents(cfg, (rank * NB + b) * bp + i) for b in range(NB) for i in range(bp)]
     noise = S.draw_pair_noise(2334, lats[0][0].shape)          # reference draw order; [2],[3] = noise A,B
-    lat = torch.cat([torch.cat(p) for p in lats]).to(dev)       # [2*bp] = A0,B0,A1,B1,...
+    lat_all = [torch.cat([torch.cat(p) for p in lats[b * bp:(b + 1) * bp]]).to(dev) for b in range(NB)]   # A0,B0,A1,B1,...
+    lat = lat_all[0]
     nz = torch.cat([noise[2], noise[3]] * bp).to(dev)
     ctx = S.make_context(cfg).to(dev)
     ia = torch.arange(0, 2 * bp, 2, dtype=torch.int32, device=dev)
@@ -209,49 +327,58 @@ def main():
         imgs = torch.cat([torch.cat(S.make_image_pair(rank * bp + i, 512)) for i in range(bp)]).to(dev)   # [2*bp,3,512,512]
         eps = torch.cat([noise[0], noise[1]] * bp).to(dev)         # the two VAE-sample draws (reference order)
 
-    def step():
+    def step(i=0):
         if a.pixels_in:
             mom = vae.moments(imgs)
             mean, logvar = mom.chunk(2, dim=1)
             z = (mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * eps) * 0.18215
             q, k, v = eng.qkv(z.contiguous(), nz, sa, sb, ctx, out=qkv)
         else:
-            q, k, v = eng.qkv(lat, nz, sa, sb, ctx, out=qkv)
+            q, k, v = eng.qkv(lat_all[i % NB], nz, sa, sb, ctx, out=qkv)
         return pair_score(q, k, v, ia, ib, eng.heads, "cosine")
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(a.warmup):
-        scores = step()
+    scores = step(0)
+    for i in range(a.warmup):
+        scores = step(i)
+    step_scores = torch.empty((a.steps, bp), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        scores = step()
-    if world > 1:                          # the only collective: gather of the scalar scores
-        allscores = [torch.empty_like(scores) for _ in range(world)]
-        dist.all_gather(allscores, scores)
+    for i in range(a.steps):
+        step_scores[i] = step(i)
+    if world > 1:                          # the only collective: one gather of the scalar scores of the whole run
+        allscores = [torch.empty_like(step_scores) for _ in range(world)]
+        dist.all_gather(allscores, step_scores)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    seen = 1
     if world > 1:
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
+        c = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(c)
+        seen = int(c.item())
+    scores = step_scores[0]
     pairs_per_s = world * a.steps * bp / el
 
     out = {
         "metric": "image-pairs/sec at 512px, SD1.5 up_blocks[0] t=600",
-        "value": round(pairs_per_s, 3), "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "value": round(pairs_per_s, 3), "unit": "pairs/s", "n_gpus": world, "n_ranks_seen": seen, "steps": a.steps,
+        "warmup": a.warmup,
         "ms_per_step": round(1e3 * el / a.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": "DiffSim SD1.5, synthetic 512px pairs (%s), up_blocks[0] t=600 (t=401), cosine"
                                % ("pixels-in incl. VAE encoder" if a.pixels_in else "latents-in"),
-                   "pairs_per_step_per_gpu": bp, "gflop_per_pair": GFLOP_PER_PAIR, "parallelism": f"pairs sharded x{world}"},
+                   "pairs_per_step_per_gpu": bp, "distinct_pairs_resident_per_gpu": bp * (1 if a.pixels_in else NB),
+                   "gflop_per_pair": GFLOP_PER_PAIR, "parallelism": f"pairs sharded x{world}"},
         "whole_path_tflops_per_gpu": round(pairs_per_s / world * GFLOP_PER_PAIR / 1e3, 2),
         "score_sample": [round(float(x), 6) for x in scores[:4].float().cpu()],
     }
@@ -304,32 +431,7 @@ def main():
             out["kernel_breakdown_ms_per_step"]["pair_tail"] = {
                 "n": 2, "ms": round(tail_ms, 3), "tflops": round(bp * 2.684e9 / (tail_ms * 1e-3) / 1e12, 1)}
         if world == 1 and not a.no_cpu_baseline:
-            # ---- CPU baseline: the oracle (fp32 torch CPU restatement) on the host cores, 1 pair,
-            # same truncated-at-the-tap schedule; also the parity check of pair 0
-            from oracle import cpu_ref as R
-            full = dict(sd)
-            for k_, shp in C.unet_param_shapes(cfg).items():
-                if k_ not in full:
-                    full[k_] = torch.zeros(shp)
-            unet = R.build_unet(R.SD15, full)
-            zA, zB = lats[0]
-            tc = time.perf_counter()
-            so = R.diffsim_latents(unet, zA, zB, noise[2], noise[3], S.make_context(cfg), 600, "up_blocks", 0, "cosine")
-            cpu_s = time.perf_counter() - tc
-            # the schedule the reference itself runs (diffsim_pipeline.py:213-221): the FULL U-Net to conv_out,
-            # batch 1, nothing cached -- same scores, about twice the work
-            tc = time.perf_counter()
-            so_full = R.diffsim_latents(unet, zA, zB, noise[2], noise[3], S.make_context(cfg), 600, "up_blocks", 0, "cosine",
-                                        full=True)
-            cpu_full_s = time.perf_counter() - tc
-            out["cpu_baseline"] = {"value": round(1.0 / cpu_s, 5), "unit": "pairs/s", "cores": torch.get_num_threads(),
-                                   "kind": "port", "sample": "1 pair (pair 0 of the batch), fp32 torch CPU oracle, "
-                                   "U-Net truncated at the tap, host cpu_count=%d" % os.cpu_count(),
-                                   "reference_schedule_value": round(1.0 / cpu_full_s, 5),
-                                   "reference_schedule": "same pair, full U-Net to conv_out as diffsim_pipeline.py:213 runs it "
-                                                         "(score %.6f)" % float(so_full)}
-            out["parity_pair0"] = {"gpu": float(scores[0]), "cpu_oracle": float(so),
-                                   "abs_err": abs(float(scores[0]) - float(so))}
+            out.update(cpu_baseline_sd15(cfg, sd, lats, noise, scores, a.cpu_pairs))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()                     # rank 0 ran one extra (profiled) step: leave together

@@ -68,6 +68,8 @@ SYMBOLS = {
     "dsim_unet_workspace_bytes": (_sz, [_vp, _i]),
     "dsim_unet_qkv": (_i, [_vp, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dsim_unet_tap_shape": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "dsim_unet_set_tap": (_i, [_vp, _i, _i, _i, _i]),
+    "dsim_unet_set_sample_size": (_i, [_vp, _i]),
     "dsim_unet_profile": (_i, [_vp, _i]),
     "dsim_unet_profile_count": (_i, [_vp]),
     "dsim_unet_profile_get": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -88,6 +90,7 @@ SYMBOLS = {
     "dsim_dit_qkv": (_i, [_vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dsim_pair_score_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "dsim_pair_score": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "dsim_pair_score_status": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "dsim_op_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "dsim_op_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsim_op_groupnorm": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp]),
@@ -112,7 +115,7 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.dsim_version() != 3:
+        if L.dsim_version() != 4:
             raise DsimError("ABI version mismatch")
         _lib = L
     return _lib

@@ -1,12 +1,30 @@
-"""Command-line flags of the reference drivers (/root/reference/argprocess.py:5-18), same names
-and defaults, plus the handful the MI355X build adds (model path, dtype, batch, GPUs)."""
+"""Command-line driver: the reference's benchmark loops on the MI355X engine.
+
+``python -m diffsim_amd --dataset cute|nights --metric diffsim|diffsim_xl|dit --model_path <dir> --image_path <dir> ...``
+
+Flags of the reference drivers (``/root/reference/argprocess.py:5-18``) keep their names, meaning and defaults;
+``--dataset`` selects which of the reference's loops runs (``cute_main.py:48-226`` or ``night_main.py:24-173`` -- separate
+scripts there), ``--model_path / --dtype / --batch / --ngpu / --noise_dtype`` are additions of this build (the reference
+hard-codes NAS checkpoint paths, ``cute_main.py:25-31``, fp16 and one GPU, ``cute_main.sh:1``).
+
+Multi-GPU (``--ngpu N``): the parent starts N rank processes before anything touches the GPU; triplets are sharded
+whole over ranks and the per-triplet scores are all-gathered (RCCL) -- rank 0 prints the accuracy.
+"""
 from __future__ import annotations
 
 import argparse
+import os
+import random
+import sys
+from typing import List, Optional, Tuple
+
+METRICS = ["diffsim", "diffsim_xl", "clip_i", "clip_cross", "dino", "dinov1", "dino_cross", "cute", "lpips", "gram",
+           "diffeats", "clipfeats", "dinofeats", "ensemble", "dit"]
+ENGINE_METRICS = ("diffsim", "diffsim_xl", "dit")
 
 
-def arg_parse(argv=None):
-    p = argparse.ArgumentParser(description="DiffSim scoring (MI355X-native engine)")
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(prog="python -m diffsim_amd", description="DiffSim scoring (MI355X-native engine)")
     p.add_argument("--image_path", type=str, help="Path to image folder")
     p.add_argument("--original_path", type=str, default=None, help="Path to original images for ipref")
     p.add_argument("--out_path", type=str, help="Path to the output folder")
@@ -14,9 +32,7 @@ def arg_parse(argv=None):
     p.add_argument("--target_block", type=str, choices=["down_blocks", "mid_blocks", "up_blocks"], default="up_blocks")
     p.add_argument("--target_layer", type=int, default=2, nargs="+")
     p.add_argument("--target_step", type=int, default=100)
-    p.add_argument("--metric", type=str, default="diffsim",
-                   choices=["diffsim", "diffsim_xl", "clip_i", "clip_cross", "dino", "dinov1", "dino_cross", "cute",
-                            "lpips", "gram", "diffeats", "clipfeats", "dinofeats", "ensemble", "dit"])
+    p.add_argument("--metric", type=str, default="diffsim", choices=METRICS)
     p.add_argument("--similarity", type=str, choices=["cosine", "mse"], default="mse")
     p.add_argument("--prompt", type=str, default="High quality image")
     p.add_argument("--ip_adapter", action="store_true")
@@ -24,7 +40,136 @@ def arg_parse(argv=None):
     p.add_argument("--use_text_attn", action="store_true")
     p.add_argument("--seed", type=int, default=2333)
     # additions of this build
-    p.add_argument("--model_path", type=str, default=None, help="diffusers-layout SD1.5 directory (unet/*.safetensors)")
-    p.add_argument("--dtype", type=str, choices=["bf16", "fp32"], default="bf16")
-    p.add_argument("--batch", type=int, default=16, help="pairs per U-Net batch")
-    return p.parse_args(argv)
+    p.add_argument("--dataset", type=str, choices=["cute", "nights"], default="cute",
+                   help="which reference loop to run: cute_main.py (class/instance/lighting tree) or night_main.py (data.csv)")
+    p.add_argument("--model_path", type=str, default=None, help="diffusers-layout checkpoint directory (unet/, vae/, text_encoder/, tokenizer/)")
+    p.add_argument("--dtype", type=str, choices=["bf16", "fp32"], default="bf16", help="engine compute dtype (fp32 = parity mode)")
+    p.add_argument("--noise_dtype", type=str, choices=["fp32", "fp16"], default="fp32",
+                   help="generator draws / add_noise arithmetic: fp32 pipeline or the reference's literal fp16 pipeline")
+    p.add_argument("--batch", type=int, default=10, help="triplets per engine batch")
+    p.add_argument("--ngpu", type=int, default=1, help="GPUs of this node to shard the triplets over (one process each)")
+    p.add_argument("--fp8_attention", action="store_true", help="--metric dit: e4m3 MFMA attention")
+    return p
+
+
+def arg_parse(argv=None):
+    return build_parser().parse_args(argv)
+
+
+# ---- the CUTE triplet walk (cute_main.py:48-108) ------------------------------------------------------------------
+def cute_triplets(image_path: str, seed: int) -> List[Tuple[str, str, str, str]]:
+    """(A, B, C, prompt) in the order the reference's loop visits them: for every class, 10 experiments, every
+    instance folder: a random lighting, two random images of it (A, B), one image of another instance under the
+    same lighting (C).  The same ``random`` call sequence as the reference (scoring consumes no ``random`` state there,
+    so collecting the triplets first is equivalent)."""
+    random.seed(seed)
+    out = []
+    ext = (".png", ".jpg", ".jpeg")
+    for cls in os.listdir(image_path):
+        if cls == "main.py" or cls == ".DS_Store":
+            continue
+        cls_dir = os.path.join(image_path, cls)
+        for _ in range(10):
+            for sub1, dirs2, _files in os.walk(cls_dir):
+                for d2 in dirs2:
+                    d2_path = os.path.join(sub1, d2)
+                    subs3 = [d for d in os.listdir(d2_path) if os.path.isdir(os.path.join(d2_path, d))]
+                    if not subs3:
+                        continue
+                    sel3 = random.choice(subs3)
+                    sel3_path = os.path.join(d2_path, sel3)
+                    files = [f for f in os.listdir(sel3_path) if f.endswith(ext)]
+                    if len(files) < 2:
+                        continue
+                    a, b = random.sample(files, 2)
+                    others = [d for d in dirs2 if d != d2]
+                    if not others:
+                        continue
+                    other3 = os.path.join(sub1, random.choice(others), sel3)
+                    ofiles = [f for f in os.listdir(other3) if f.endswith(ext)]
+                    if not ofiles:
+                        continue
+                    c = random.choice(ofiles)
+                    out.append((os.path.join(sel3_path, a), os.path.join(sel3_path, b), os.path.join(other3, c),
+                                f"The photo of a {cls}"))
+    return out
+
+
+def cute_counts(s_ab, s_ac, similarity: str) -> Tuple[int, int]:
+    """correct / correct_2x of cute_main.py:196-205 (a NaN score compares False: counted wrong, as there)."""
+    if similarity == "mse":
+        return int((s_ab < s_ac).sum()), int((s_ab * 2 < s_ac).sum())
+    return int((s_ab > s_ac).sum()), int((s_ab > 2 * s_ac).sum())
+
+
+def build_scorer(args):
+    """Flags -> scorer object (DiffSim / diffsim_xl / diffsim_DiT): the object graph of cute_main.py:25-31."""
+    import torch
+    from . import loader
+    if args.metric not in ENGINE_METRICS:
+        raise SystemExit(f"--metric {args.metric}: only the DiffSim metrics (diffsim, diffsim_xl, dit) run on this engine; the "
+                         f"competitor metrics of the reference are out of scope")
+    if args.ip_adapter:
+        raise SystemExit("--ip_adapter: IP-Adapter mode is out of scope of this build")
+    if not args.model_path:
+        raise SystemExit("--model_path is required (no checkpoint is bundled)")
+    nd = torch.float16 if args.noise_dtype == "fp16" else torch.float32
+    dev = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+    if args.metric == "diffsim":
+        return loader.load_diffsim(args.model_path, args.dtype, dev, nd)
+    if args.metric == "diffsim_xl":
+        return loader.load_diffsim_xl(args.model_path, args.dtype, dev, nd)
+    return loader.load_diffsim_dit(args.model_path, args.image_size, args.target_step, args.dtype, dev, args.fp8_attention)
+
+
+def run(args) -> int:
+    import torch
+    from . import harness as H
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+    scorer = build_scorer(args)
+    layer = args.target_layer if isinstance(args.target_layer, list) else [args.target_layer]
+    if rank == 0:
+        print(f"=========seed {args.seed}=========")
+        print(f"Experiment on {args.target_block}, layer {args.target_layer}, timestep {args.target_step}:")
+    if args.dataset == "nights":
+        rows = H.read_nights_csv(args.image_path)
+        trip = [(r["ref"], r["left"], r["right"], r["prompt"]) for r in rows]
+    else:
+        trip = cute_triplets(args.image_path, args.seed)
+    s_ab, s_ac, bad = H.score_path_triplets(scorer, trip, args.image_size, args.target_block, layer, args.target_step, args.seed,
+                                            args.similarity, rank, world, args.batch)
+    if rank == 0:
+        total = len(trip)
+        if bad:
+            print(f"WARNING: {bad} pair score(s) are NaN/inf (counted as wrong, as the reference's comparisons would)")
+        if args.dataset == "nights":
+            acc = H.nights_accuracy(s_ab, s_ac, [r["vote"] for r in rows], args.similarity)
+            print(f"Final validation accuracy: {acc:.2f}%")
+        else:
+            correct, correct2 = cute_counts(s_ab.cpu(), s_ac.cpu(), args.similarity)
+            print(f"Total comparisons: {total}")
+            if total > 0:
+                print(f"Total {total}; Correct {correct}; Correct 2x {correct2}")
+                print(f"Accuracy: {correct / total * 100}%")
+                print(f"2x Accuracy: {correct2 / total * 100}%")
+            else:
+                print("No valid comparisons were made.")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = arg_parse(argv)
+    if args.ngpu > 1 and "WORLD_SIZE" not in os.environ:
+        from .parallel import spawn_ranks              # the parent never touches the GPU
+        return spawn_ranks(args.ngpu, [sys.executable, "-m", "diffsim_amd"] + argv)
+    return run(args)

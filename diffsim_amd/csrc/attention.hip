@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void pair_tail_kernel(const T* __restrict__ qg
 // one thread per pair: fixed-order f64 fold of the partials, then cosine / mse and the mean of
 // the two directions (diffsim.py:187-197; F.cosine_similarity eps = 1e-8)
 __global__ void pair_finish_kernel(const float* __restrict__ part, int n_pairs, int nblk, int mse, double count,
-                                   float* __restrict__ out) {
+                                   float* __restrict__ out, int32_t* __restrict__ status) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     double res = 0.0;
@@ -498,7 +498,10 @@ __global__ void pair_finish_kernel(const float* __restrict__ part, int n_pairs, 
             res += a / (fmax(nx, 1e-8) * fmax(ny, 1e-8));
         }
     }
-    out[p] = (float)(res * 0.5);
+    const float sc = (float)(res * 0.5);
+    out[p] = sc;
+    // NaN guard: non-finite features surface here as a non-finite score; report them per pair
+    if (status) status[p] = (sc - sc == 0.0f) ? 0 : 1;
 }
 
 inline float scale_log2_of(int D) { return (1.0f / sqrtf((float)D)) * 1.4426950408889634f; }
@@ -506,12 +509,9 @@ inline float scale_log2_of(int D) { return (1.0f / sqrtf((float)D)) * 1.44269504
 template <typename T, int D>
 int launch_attn_d(const AttnArgs& a, hipStream_t s) {
     typedef ACfg<T, D> C;
-    static bool attr_done = false;
+    static DeviceOnce once;
     auto kern = attn_kernel<T, D>;
-    if (!attr_done) {
-        DSIM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        attr_done = true;
-    }
+    CK_ONCE(once, kern, C::LDS);
     hipLaunchKernelGGL(kern, dim3(((a.Nq + 127) / 128) * a.H * a.B), dim3(256), C::LDS, s, a, scale_log2_of(D));
     DSIM_HIP_CHECK(hipGetLastError());
     return DSIM_OK;
@@ -532,28 +532,25 @@ int launch_attn_t(const AttnArgs& a, hipStream_t s) {
 
 template <typename T, int D>
 int launch_tail_d(const void* q, const void* k, const void* v, const int32_t* ia, const int32_t* ib, int n_pairs,
-                  int B, int H, int N, int mse, float* out, void* scratch, hipStream_t s) {
+                  int B, int H, int N, int mse, float* out, void* scratch, hipStream_t s, int32_t* status) {
     typedef ACfg<T, D> C;
-    static bool attr_done = false;
+    static DeviceOnce once;
     auto kern = pair_tail_kernel<T, D>;
-    if (!attr_done) {
-        DSIM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        attr_done = true;
-    }
+    CK_ONCE(once, kern, C::LDS);
     const int qt = (N + 127) / 128;
     hipLaunchKernelGGL(kern, dim3(qt, B * H, n_pairs * 2), dim3(256), C::LDS, s, (const T*)q, (const T*)k,
                        (const T*)v, ia, ib, B, H, N, scale_log2_of(D), mse, (float*)scratch);
     hipLaunchKernelGGL(pair_finish_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, s, (const float*)scratch, n_pairs,
-                       qt * B * H, mse, (double)B * H * N * D, out);
+                       qt * B * H, mse, (double)B * H * N * D, out, status);
     DSIM_HIP_CHECK(hipGetLastError());
     return DSIM_OK;
 }
 
 template <typename T>
 int launch_tail_t(const void* q, const void* k, const void* v, const int32_t* ia, const int32_t* ib, int n_pairs,
-                  int B, int H, int N, int D, int mse, float* out, void* scratch, hipStream_t s) {
+                  int B, int H, int N, int D, int mse, float* out, void* scratch, hipStream_t s, int32_t* status) {
     switch (D) {
-#define X(d) case d: return launch_tail_d<T, d>(q, k, v, ia, ib, n_pairs, B, H, N, mse, out, scratch, s);
+#define X(d) case d: return launch_tail_d<T, d>(q, k, v, ia, ib, n_pairs, B, H, N, mse, out, scratch, s, status);
         DSIM_FOR_EACH_D(X)
 #undef X
         default: return DSIM_ERR_INVALID;
@@ -578,12 +575,12 @@ size_t pair_score_scratch_bytes(int n_pairs, int B, int H, int N, int D) {
 
 int launch_pair_score(const void* q, const void* k, const void* v, const int32_t* ia, const int32_t* ib,
                       int n_pairs, int B, int H, int N, int D, int dtype, int similarity, float* out, void* scratch,
-                      size_t scratch_bytes, hipStream_t s) {
+                      size_t scratch_bytes, hipStream_t s, int32_t* status) {
     if (n_pairs <= 0 || D % 8 || N < 1) return DSIM_ERR_INVALID;
     if (scratch_bytes < pair_score_scratch_bytes(n_pairs, B, H, N, D)) return DSIM_ERR_WORKSPACE;
     if (n_pairs * 2 > 65535) return DSIM_ERR_INVALID;
-    if (dtype == DSIM_BF16) return launch_tail_t<bf16>(q, k, v, ia, ib, n_pairs, B, H, N, D, similarity, out, scratch, s);
-    if (dtype == DSIM_F32) return launch_tail_t<float>(q, k, v, ia, ib, n_pairs, B, H, N, D, similarity, out, scratch, s);
+    if (dtype == DSIM_BF16) return launch_tail_t<bf16>(q, k, v, ia, ib, n_pairs, B, H, N, D, similarity, out, scratch, s, status);
+    if (dtype == DSIM_F32) return launch_tail_t<float>(q, k, v, ia, ib, n_pairs, B, H, N, D, similarity, out, scratch, s, status);
     return DSIM_ERR_INVALID;
 }
 

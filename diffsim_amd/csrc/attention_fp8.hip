@@ -243,12 +243,9 @@ __global__ __launch_bounds__(256, 2) void attn_fp8_kernel(const AttnArgs p, cons
 template <int D>
 int launch_f8(const AttnArgs& a, hipStream_t s) {
     typedef F8Cfg<D> C;
-    static bool attr_done = false;
+    static DeviceOnce once;
     auto kern = attn_fp8_kernel<D>;
-    if (!attr_done) {
-        DSIM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS));
-        attr_done = true;
-    }
+    CK_ONCE(once, kern, C::LDS);
     const float sl2 = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
     hipLaunchKernelGGL(kern, dim3(((a.Nq + 127) / 128) * a.H * a.B), dim3(256), C::LDS, s, a, sl2);
     DSIM_HIP_CHECK(hipGetLastError());

@@ -113,6 +113,30 @@ int launch_attention_fp8(const AttnArgs& a, hipStream_t s);      // bf16 in/out,
 size_t pair_score_scratch_bytes(int n_pairs, int B, int H, int N, int D);
 int launch_pair_score(const void* q, const void* k, const void* v, const int32_t* idx_a,
                       const int32_t* idx_b, int n_pairs, int B, int H, int N, int D, int dtype,
-                      int similarity, float* out, void* scratch, size_t scratch_bytes, hipStream_t s);
+                      int similarity, float* out, void* scratch, size_t scratch_bytes, hipStream_t s,
+                      int32_t* status = nullptr);
+
+// Per-device once-flags for hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count: the attribute is a
+// per-device property of the function, so a process that drives several devices must set it on each.
+int cu_count();
+struct DeviceOnce {
+    unsigned long long done = 0;       // bit d set: attribute applied on device d (d < 64)
+    template <typename F> int ensure(F&& apply) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return DSIM_ERR_HIP;
+        if (dev >= 0 && dev < 64 && (__atomic_load_n(&done, __ATOMIC_ACQUIRE) >> dev) & 1ull) return DSIM_OK;
+        const int st = apply();          // idempotent: two racing threads may both apply it
+        if (st == DSIM_OK && dev >= 0 && dev < 64) __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELEASE);
+        return st;
+    }
+};
+#define CK_ONCE(once, kern, lds_bytes)                                                                                   \
+    do {                                                                                                                 \
+        const int _st = (once).ensure([&]() -> int {                                                                     \
+            return hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (lds_bytes)) ==  \
+                           hipSuccess ? DSIM_OK : DSIM_ERR_HIP;                                                          \
+        });                                                                                                              \
+        if (_st != DSIM_OK) return _st;                                                                                  \
+    } while (0)
 
 }  // namespace dsim

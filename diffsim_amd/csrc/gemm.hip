@@ -489,27 +489,30 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     }
 }
 
+}  // namespace
+
 int cu_count() {
-    static int n = 0;
+    static int per_dev[64] = {0};      // CU count of each device this process has launched on
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = __atomic_load_n(&per_dev[dev], __ATOMIC_RELAXED);
     if (!n) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        __atomic_store_n(&per_dev[dev], n, __ATOMIC_RELAXED);
     }
     return n;
 }
+
+namespace {
 
 template <typename T, int BM, int BN, int MODE, bool GEGLU, int WM, int WN, int EK>
 int launch_ek(const GemmArgs& a, hipStream_t s) {
     constexpr int NW = WM * WN;
     constexpr int LDS = gemm_lds_bytes<T, BM, BN, GEGLU, WM, WN>();
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;   // one handle per device / one host thread per handle
+    static DeviceOnce once;          // the LDS opt-in is a per-device attribute of the function
     auto kern = gemm_kernel<T, BM, BN, MODE, GEGLU, WM, WN, EK>;
-    if (!attr_done) {
-        DSIM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_done = true;
-    }
+    CK_ONCE(once, kern, LDS);
     const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
     // byte extents of the three operands for the buffer descriptors (32-bit offsets: < 2 GiB each)
     GemmArgs g = a;

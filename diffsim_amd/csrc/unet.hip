@@ -561,6 +561,29 @@ int dsim_unet_tap_shape(const dsim_unet* h, int* tokens, int* heads, int* head_d
     return tap_geometry(h->cfg, tokens, heads, head_dim);
 }
 
+int dsim_unet_set_tap(dsim_unet* h, int tap_block, int tap_layer, int tap_attn, int tap_tfm) {
+    if (!h) return DSIM_ERR_INVALID;
+    if (!h->finalized) return DSIM_ERR_STATE;
+    const dsim_unet_cfg old = h->cfg;
+    h->cfg.tap_block = tap_block; h->cfg.tap_layer = tap_layer; h->cfg.tap_attn = tap_attn; h->cfg.tap_tfm = tap_tfm;
+    int t, hh, d;
+    int st = tap_geometry(h->cfg, &t, &hh, &d);
+    if (st == DSIM_OK) {             // every parameter up to the new tap must have been loaded: dry walk
+        Arena ar;
+        Walk w{h, &ar, nullptr, 2, false};
+        st = w.go(nullptr, nullptr, 0.f, 0.f, nullptr);
+    }
+    if (st != DSIM_OK) h->cfg = old;
+    return st;
+}
+
+int dsim_unet_set_sample_size(dsim_unet* h, int side) {
+    if (!h || side < 1) return DSIM_ERR_INVALID;
+    if (side % (1 << (h->cfg.n_levels - 1))) return DSIM_ERR_INVALID;
+    h->cfg.sample_size = side;
+    return DSIM_OK;
+}
+
 int dsim_unet_qkv(dsim_unet* h, const float* latents, const float* noise, float sqrt_abar, float sqrt_1m_abar,
                   const float* ctx, int n_images, void* q, void* k, void* v, void* workspace, size_t workspace_bytes,
                   void* stream) {
@@ -628,6 +651,18 @@ int dsim_pair_score(const void* q, const void* k, const void* v, const int32_t* 
     if (workspace_bytes < lost) return DSIM_ERR_WORKSPACE;
     return launch_pair_score(q, k, v, idx_a, idx_b, n_pairs, B, H, N, D, dtype, similarity, out_scores, (void*)b0,
                              workspace_bytes - lost, (hipStream_t)stream);
+}
+
+int dsim_pair_score_status(const void* q, const void* k, const void* v, const int32_t* idx_a, const int32_t* idx_b,
+                           int n_pairs, int B, int H, int N, int D, int dtype, int similarity, float* out_scores,
+                           int32_t* status, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!q || !k || !v || !idx_a || !idx_b || !out_scores || !status || !workspace) return DSIM_ERR_INVALID;
+    if (similarity != 0 && similarity != 1) return DSIM_ERR_INVALID;
+    const uintptr_t b0 = ((uintptr_t)workspace + 255) & ~(uintptr_t)255;
+    const size_t lost = b0 - (uintptr_t)workspace;
+    if (workspace_bytes < lost) return DSIM_ERR_WORKSPACE;
+    return launch_pair_score(q, k, v, idx_a, idx_b, n_pairs, B, H, N, D, dtype, similarity, out_scores, (void*)b0,
+                             workspace_bytes - lost, (hipStream_t)stream, status);
 }
 
 // ---- single-operator entry points (tests / micro-benchmarks; these allocate and synchronise) ----

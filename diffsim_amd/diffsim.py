@@ -55,7 +55,7 @@ class DiffSim:
     def __init__(self, torch_dtype=torch.bfloat16, device="cuda", ip_adapter=False, *,
                  unet_config: UNetConfig = SD15, state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  vae=None, encode_prompt: Optional[Callable[[str], torch.Tensor]] = None,
-                 vae_dtype=torch.float16, use_graphs: bool = False):
+                 vae_dtype=torch.float16, use_graphs: bool = False, noise_dtype=torch.float32):
         if ip_adapter:
             raise NotImplementedError("IP-Adapter mode is out of scope (SURVEY.md section 2 row 3)")
         if state_dict is None:
@@ -71,17 +71,33 @@ class DiffSim:
         self.vae_dtype = vae_dtype
         self._encode_prompt = encode_prompt
         self.use_graphs = use_graphs            # replay each U-Net forward as one hipGraph (small, launch-bound batches)
-        self._engines: Dict[Tuple[str, int], UNetEngine] = {}
+        # dtype of the generator draws and of the add_noise arithmetic.  float32 = the reference run as an fp32 CPU
+        # pipeline (the north_star parity setting).  float16 = the reference as its drivers construct it
+        # (DiffSim(torch.float16), diffsim.py:79-83): randn_tensor(dtype=latents.dtype) draws in fp16 -- a different
+        # random stream from the fp32 draw of the same seed -- the VAE sample is drawn in fp16 too, and
+        # scheduler.add_noise runs in fp16 (diffsim_pipeline.py:174-183)
+        if noise_dtype not in (torch.float32, torch.float16):
+            raise ValueError("noise_dtype must be torch.float32 or torch.float16")
+        self.noise_dtype = noise_dtype
+        if vae is not None and hasattr(vae, "sample_dtype"):
+            vae.sample_dtype = noise_dtype
+        self._base: Optional[UNetEngine] = None
+        self._engines: Dict[Tuple[str, int], object] = {}
         self._ctx: Dict[str, torch.Tensor] = {}
         self._pool = ThreadPoolExecutor(max_workers=16)     # host-side image decode / resize
 
     # ------------------------------------------------------------------------------------------
     def engine(self, target_block: str, target_layer: int) -> UNetEngine:
+        """The engine positioned at a tap.  ONE packed weight copy (per scorer, i.e. per dtype) serves every tap:
+        the handle's tap is moved, nothing is re-packed."""
         key = (target_block, int(target_layer))
         if key not in self._engines:
-            self._engines[key] = UNetEngine(self.cfg, self.state_dict, self.dtype, target_block, target_layer,
-                                            str(self.device))
-            self._engines[key].use_graphs = self.use_graphs
+            if self._base is None:
+                self._base = UNetEngine(self.cfg, self.state_dict, self.dtype, target_block, int(target_layer),
+                                        str(self.device))
+                self._base.use_graphs = self.use_graphs
+            self._engines[key] = self._base.view(target_block, int(target_layer))
+            self._engines[key].tokens            # moves the tap once: a missing weight raises here, not mid-run
         return self._engines[key]
 
     def context(self, prompt: Union[str, torch.Tensor]) -> torch.Tensor:
@@ -114,8 +130,8 @@ class DiffSim:
             x = torch.cat([tensor_A, tensor_B]).to(vae.device).to(dtype=self.vae_dtype)
             mom = vae.moments(x)
             sf = vae.config.scaling_factor
-            return (sf * _LatentDist(mom[0:1]).sample(generator=generator),
-                    sf * _LatentDist(mom[1:2]).sample(generator=generator))
+            return (sf * _LatentDist(mom[0:1], self.noise_dtype).sample(generator=generator),
+                    sf * _LatentDist(mom[1:2], self.noise_dtype).sample(generator=generator))
         return (self.prepare_image_latents(tensor_A, vae, None, generator),
                 self.prepare_image_latents(tensor_B, vae, None, generator))
 
@@ -127,6 +143,16 @@ class DiffSim:
         t = sched.timestep_from_index(int(target_step))
         eng.set_timestep(t)
         sa, sb = sched.noise_coefficients(t)
+        if self.noise_dtype == torch.float16:
+            # PNDMScheduler.add_noise on fp16 tensors: alphas_cumprod cast to fp16, sqrt and 1-x in fp16, the two
+            # products and the sum each rounded to fp16 (elementwise, so the batch can be done on the device)
+            dev = self.device
+            ac = sched.alphas_cumprod()[t].to(torch.float16)
+            a16, b16 = ac ** 0.5, (1 - ac) ** 0.5
+            xt = a16.to(dev) * latents.to(dev, torch.float16) + b16.to(dev) * noise.to(dev, torch.float16)
+            lat = xt.float().contiguous()
+            ctx16 = self.context(prompt).to(torch.float16).float()         # the fp16 text encoder's output
+            return eng.qkv(lat, torch.zeros_like(lat), 1.0, 0.0, ctx16)
         lat = latents.to(self.device, torch.float32).contiguous()
         nz = noise.to(self.device, torch.float32).contiguous()
         return eng.qkv(lat, nz, sa, sb, self.context(prompt))
@@ -173,10 +199,12 @@ class DiffSim:
         generator = get_generator(seed, "cpu")                   # reference CPU path: CPU generator
         latentsA, latentsB = self._pair_latents(tensor_A, tensor_B, generator)
         # DiffSimPipeline.step draws the noise right after prepare_latents: A's step first, then B's
-        noiseA = torch.randn(latentsA.shape, generator=generator, dtype=torch.float32)
-        noiseB = torch.randn(latentsB.shape, generator=generator, dtype=torch.float32)
-        return self.score_latent_pairs(latentsA.float(), latentsB.float(), noiseA, noiseB, prompt, target_block,
-                                       target_layer, target_step, similarity)
+        noiseA = torch.randn(latentsA.shape, generator=generator, dtype=self.noise_dtype)
+        noiseB = torch.randn(latentsB.shape, generator=generator, dtype=self.noise_dtype)
+        if self.noise_dtype == torch.float16:      # the fp16 pipeline holds its latents in fp16
+            latentsA, latentsB = latentsA.to(torch.float16), latentsB.to(torch.float16)
+        return self.score_latent_pairs(latentsA.float(), latentsB.float(), noiseA.float(), noiseB.float(), prompt,
+                                       target_block, target_layer, target_step, similarity)
 
     @torch.no_grad()
     def score_pairs(self, pairs: Sequence[Tuple[str, str]], img_size, prompt, target_block, target_layer, target_step,
@@ -206,13 +234,14 @@ class DiffSim:
                 d = _LatentDist(vae.moments(x))
                 if eps is None:
                     shp = (1,) + tuple(d.mean.shape[1:])
-                    eA = torch.randn(shp, generator=g, dtype=torch.float32).to(vae.device)
-                    eB = torch.randn(shp, generator=g, dtype=torch.float32).to(vae.device)
-                    nA = torch.randn(shp, generator=g, dtype=torch.float32)
-                    nB = torch.randn(shp, generator=g, dtype=torch.float32)
+                    nd = self.noise_dtype
+                    eA = torch.randn(shp, generator=g, dtype=nd).float().to(vae.device)
+                    eB = torch.randn(shp, generator=g, dtype=nd).float().to(vae.device)
+                    nA = torch.randn(shp, generator=g, dtype=nd).float()
+                    nB = torch.randn(shp, generator=g, dtype=nd).float()
                     eps = (eA, eB)
-                lA.append((sf * (d.mean[0::2] + d.std[0::2] * eps[0])).float())
-                lB.append((sf * (d.mean[1::2] + d.std[1::2] * eps[1])).float())
+                lA.append((sf * (d.mean[0::2] + d.std[0::2] * eps[0])).to(self.noise_dtype).float())
+                lB.append((sf * (d.mean[1::2] + d.std[1::2] * eps[1])).to(self.noise_dtype).float())
             return self.score_latent_pairs(torch.cat(lA), torch.cat(lB), nA, nB, prompt, target_block, target_layer,
                                            target_step, similarity, batch_pairs)
         for pa, pb in pairs:
@@ -220,9 +249,9 @@ class DiffSim:
             a = self.prepare_image_latents(process_image(load_image(pa), img_size), self.vae, None, generator)
             b = self.prepare_image_latents(process_image(load_image(pb), img_size), self.vae, None, generator)
             if nA is None:   # same seed every call -> the two noise tensors are identical for every pair
-                nA = torch.randn(a.shape, generator=generator, dtype=torch.float32)
-                nB = torch.randn(b.shape, generator=generator, dtype=torch.float32)
-            lA.append(a.float())
-            lB.append(b.float())
+                nA = torch.randn(a.shape, generator=generator, dtype=self.noise_dtype).float()
+                nB = torch.randn(b.shape, generator=generator, dtype=self.noise_dtype).float()
+            lA.append(a.to(self.noise_dtype).float())
+            lB.append(b.to(self.noise_dtype).float())
         return self.score_latent_pairs(torch.cat(lA), torch.cat(lB), nA, nB, prompt, target_block, target_layer,
                                        target_step, similarity, batch_pairs)

@@ -111,14 +111,41 @@ class UNetEngine:
             torch.cuda.synchronize(self.device)
             _lib.check(self.L.dsim_unet_finalize(self._h, _stream_ptr()), "dsim_unet_finalize")
             del keep
-        n, h, d = C.c_int(), C.c_int(), C.c_int()
-        _lib.check(self.L.dsim_unet_tap_shape(self._h, C.byref(n), C.byref(h), C.byref(d)), "tap_shape")
-        self.tokens, self.heads, self.head_dim = n.value, h.value, d.value
+        self.sample_size = cfg.sample_size
+        self._refresh_tap_shape()
         self._ws: Optional[torch.Tensor] = None
         self._graphs: Dict[tuple, tuple] = {}
         self.use_graphs = False
         self._profiling = False
         self._t = None
+
+    def _refresh_tap_shape(self):
+        n, h, d = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self.L.dsim_unet_tap_shape(self._h, C.byref(n), C.byref(h), C.byref(d)), "tap_shape")
+        self.tokens, self.heads, self.head_dim = n.value, h.value, d.value
+        self._max_images = None
+
+    def set_tap(self, target_block: str, target_layer):
+        """Move the tap; the packed weights are shared (one copy per dtype serves every --target_block /
+        --target_layer).  Raises if a parameter needed before the new tap was never loaded."""
+        if (target_block, target_layer) == (self.target_block, self.target_layer):
+            return
+        tl, ta, tt = resolve_tap(self.cfg, target_block, target_layer)
+        _lib.check(self.L.dsim_unet_set_tap(self._h, _lib.TAP[target_block], tl, ta, tt), "dsim_unet_set_tap")
+        self.target_block, self.target_layer = target_block, target_layer
+        self._refresh_tap_shape()
+        self._graphs.clear()
+
+    def set_sample_size(self, side: int):
+        """Latent side of the next qkv() calls (cfg.sample_size is the default, not a limit)."""
+        if side != self.sample_size:
+            _lib.check(self.L.dsim_unet_set_sample_size(self._h, int(side)), "dsim_unet_set_sample_size")
+            self.sample_size = int(side)
+            self._refresh_tap_shape()
+            self._graphs.clear()
+
+    def view(self, target_block: str, target_layer) -> "TapView":
+        return TapView(self, target_block, target_layer)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -199,9 +226,10 @@ class UNetEngine:
         if latents.dtype != torch.float32 or noise.dtype != torch.float32 or ctx.dtype != torch.float32:
             raise _lib.DsimError("latents, noise and ctx must be float32")
         n = latents.shape[0]
-        s = self.cfg.sample_size
-        if tuple(latents.shape) != (n, self.cfg.in_channels, s, s) or noise.shape != latents.shape:
-            raise _lib.DsimError(f"latents must be (n,{self.cfg.in_channels},{s},{s})")
+        if latents.ndim != 4 or latents.shape[1] != self.cfg.in_channels or latents.shape[2] != latents.shape[3] or \
+                noise.shape != latents.shape:
+            raise _lib.DsimError(f"latents and noise must be (n,{self.cfg.in_channels},s,s)")
+        self.set_sample_size(int(latents.shape[2]))
         if tuple(ctx.shape) != (2, self.cfg.ctx_len, self.cfg.cross_attention_dim):
             raise _lib.DsimError("ctx must be (2, ctx_len, cross_attention_dim)")
         with torch.cuda.device(self.device):
@@ -249,9 +277,27 @@ class UNetEngine:
         return tuple(t.clone() for t in st["out"])
 
 
+class TapView:
+    """One (target_block, target_layer) of a shared UNetEngine: every attribute access first moves the engine's tap
+    there, so several taps can be used alternately over ONE packed weight copy."""
+
+    def __init__(self, base: UNetEngine, target_block: str, target_layer):
+        object.__setattr__(self, "_base", base)
+        object.__setattr__(self, "_tap", (target_block, target_layer))
+
+    def __getattr__(self, name):
+        base = object.__getattribute__(self, "_base")
+        base.set_tap(*object.__getattribute__(self, "_tap"))
+        return getattr(base, name)
+
+    def __setattr__(self, name, value):
+        setattr(object.__getattribute__(self, "_base"), name, value)
+
+
 def pair_score(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, idx_a: torch.Tensor, idx_b: torch.Tensor,
-               heads: int, similarity: str = "cosine") -> torch.Tensor:
-    """Fused score tail (diffsim/diffsim.py:177-197).  q,k,v: [n_feat][B][N][H*D]; idx: int32 cuda [n_pairs]."""
+               heads: int, similarity: str = "cosine", return_status: bool = False):
+    """Fused score tail (diffsim/diffsim.py:177-197).  q,k,v: [n_feat][B][N][H*D]; idx: int32 cuda [n_pairs].
+    return_status: also return an int32 [n_pairs] tensor, 1 where the score is NaN / infinite (NaN guard)."""
     L = _lib.lib()
     _require_cuda(q, k, v, idx_a, idx_b)
     if similarity not in ("cosine", "mse"):
@@ -267,6 +313,13 @@ def pair_score(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, idx_a: torch.T
     with torch.cuda.device(q.device):
         wsb = int(L.dsim_pair_score_workspace_bytes(n_pairs, B, heads, N, D))
         ws = torch.empty(wsb, dtype=torch.uint8, device=q.device)
+        if return_status:
+            status = torch.empty(n_pairs, dtype=torch.int32, device=q.device)
+            _lib.check(L.dsim_pair_score_status(q.data_ptr(), k.data_ptr(), v.data_ptr(), idx_a.data_ptr(), idx_b.data_ptr(),
+                                                n_pairs, B, heads, N, D, _TORCH2DSIM[q.dtype],
+                                                0 if similarity == "cosine" else 1, out.data_ptr(), status.data_ptr(),
+                                                ws.data_ptr(), wsb, _stream_ptr()), "dsim_pair_score_status")
+            return out, status
         _lib.check(L.dsim_pair_score(q.data_ptr(), k.data_ptr(), v.data_ptr(), idx_a.data_ptr(), idx_b.data_ptr(),
                                      n_pairs, B, heads, N, D, _TORCH2DSIM[q.dtype], 0 if similarity == "cosine" else 1,
                                      out.data_ptr(), ws.data_ptr(), wsb, _stream_ptr()), "dsim_pair_score")
@@ -345,23 +398,26 @@ class _LatentDist:
     (diffsim/diffsim.py:94).  mean/logvar live on the device; the noise is drawn with the caller's
     generator on ITS device (CPU in the reference-CPU-path setting) in the reference's order."""
 
-    def __init__(self, moments: torch.Tensor):
+    def __init__(self, moments: torch.Tensor, sample_dtype: torch.dtype = torch.float32):
         self.mean, logvar = moments.chunk(2, dim=1)
         self.logvar = logvar.clamp(-30.0, 20.0)
         self.std = torch.exp(0.5 * self.logvar)
+        # dtype of the sample draw: diffusers draws randn_tensor(dtype=parameters.dtype), i.e. fp16 under the
+        # reference's fp16 SD1.5 pipeline -- a different random stream from the fp32 draw of the same generator
+        self.sample_dtype = sample_dtype
 
     def sample(self, generator=None) -> torch.Tensor:
         gdev = generator.device if generator is not None else self.mean.device
-        eps = torch.randn(self.mean.shape, generator=generator, dtype=torch.float32, device=gdev)
-        return self.mean + self.std * eps.to(self.mean.device)
+        eps = torch.randn(self.mean.shape, generator=generator, dtype=self.sample_dtype, device=gdev)
+        return self.mean + self.std * eps.to(self.mean.device, torch.float32)
 
     def mode(self) -> torch.Tensor:
         return self.mean
 
 
 class _EncodeOut:
-    def __init__(self, moments):
-        self.latent_dist = _LatentDist(moments)
+    def __init__(self, moments, sample_dtype=torch.float32):
+        self.latent_dist = _LatentDist(moments, sample_dtype)
 
 
 class VAEEncoder:
@@ -401,6 +457,7 @@ class VAEEncoder:
             _lib.check(self.L.dsim_vae_finalize(self._h, _stream_ptr()), "dsim_vae_finalize")
             del keep
         self._ws = None
+        self.sample_dtype = torch.float32      # dtype of latent_dist.sample's draw (DiffSim(noise_dtype=...) sets it)
 
     def __del__(self):
         try:
@@ -435,7 +492,7 @@ class VAEEncoder:
         return out
 
     def encode(self, images: torch.Tensor) -> _EncodeOut:
-        return _EncodeOut(self.moments(images))
+        return _EncodeOut(self.moments(images), self.sample_dtype)
 
 
 # ---- DiT backbone ---------------------------------------------------------

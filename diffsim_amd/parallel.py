@@ -8,10 +8,41 @@ backend on GPUs; gloo on CPU in the tests).  4 bytes per pair: latency-bound, no
 """
 from __future__ import annotations
 
+import os
+import socket
+import subprocess
+import sys
 from typing import List, Sequence
 
 import torch
 import torch.distributed as dist
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n: int, cmd: Sequence[str]) -> int:
+    """Start `n` fresh rank processes of `cmd` on this node (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, rendezvous on 127.0.0.1) and wait for them; returns the first non-zero exit code.  The caller must
+    not have touched the GPU: nothing is exec'ed from a GPU-initialised process, the ranks are plain children."""
+    env0 = dict(os.environ)
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env0["MASTER_ADDR"] = "127.0.0.1"
+    env0["MASTER_PORT"] = str(free_port())
+    env0["WORLD_SIZE"] = env0["LOCAL_WORLD_SIZE"] = str(n)
+    procs = [subprocess.Popen(list(cmd), env=dict(env0, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+    rc = 0
+    for r, p in enumerate(procs):
+        c = p.wait()
+        if c != 0:
+            print(f"rank {r} exited with code {c}", file=sys.stderr, flush=True)
+            rc = rc or c
+    return rc
 
 
 def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
@@ -54,7 +85,10 @@ def score_pairs_sharded(scorer, latA: torch.Tensor, latB: torch.Tensor, noiseA, 
     idx = shard_indices(n, rank, world)
     if idx:
         sel = torch.tensor(idx, dtype=torch.long)
-        local = scorer.score_latent_pairs(latA[sel], latB[sel], noiseA, noiseB, prompt, **kw)
+        # per-pair noise (n,4,s,s) is sharded with the pairs; a shared (1,4,s,s) draw is passed through
+        nA = noiseA[sel] if torch.is_tensor(noiseA) and noiseA.shape[0] == n and n > 1 else noiseA
+        nB = noiseB[sel] if torch.is_tensor(noiseB) and noiseB.shape[0] == n and n > 1 else noiseB
+        local = scorer.score_latent_pairs(latA[sel], latB[sel], nA, nB, prompt, **kw)
     else:
         local = torch.empty(0, dtype=torch.float32, device=scorer.device)
     return gather_scores(local, n, rank, world)

@@ -9,7 +9,8 @@
  *   - the callee never allocates after dsim_unet_finalize(), never frees caller memory,
  *     never synchronises the stream and never throws: it returns 0 or a negative
  *     dsim_status code (dsim_strerror() gives the text);
- *   - one handle per device, one host thread per handle, re-entrant across handles;
+ *   - one handle per device, one host thread per handle, re-entrant across handles (per-kernel launch attributes
+ *     are cached per device, so handles on several devices may live in one process);
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream).
  *
  * Layouts: activations are token-major ("NHWC"): [batch][pixel][channel].  Q/K/V leave the
@@ -26,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DSIM_ABI_VERSION 3
+#define DSIM_ABI_VERSION 4
 
 typedef enum dsim_status {
     DSIM_OK = 0,
@@ -138,6 +139,16 @@ int  dsim_unet_profile_get(dsim_unet* h, int i, char* name, int name_cap, double
 /* geometry of the tap for the current cfg: tokens, heads, head_dim */
 int  dsim_unet_tap_shape(const dsim_unet* h, int* tokens, int* heads, int* head_dim);
 
+/* Move the tap of a finalized handle (same meaning as the cfg fields of the same names): the packed weights are
+ * shared by every tap, only the point where the walk stops changes -- one weight copy serves
+ * --target_block/--target_layer sweeps (diffsim/diffsim.py:122-145, diffsim/diffsim_xl.py:88-107).
+ * DSIM_ERR_MISSING_WEIGHT when a parameter needed before the new tap was never loaded (the old tap stays). */
+int  dsim_unet_set_tap(dsim_unet* h, int tap_block, int tap_layer, int tap_attn, int tap_tfm);
+/* Latent side of the next dsim_unet_qkv calls (cfg.sample_size is only the default): the reference runs any
+ * --image_size through the same weights (argprocess.py:8: default 512 px, SDXL native 1024 px).  `side` must be a
+ * multiple of 2^(n_levels-1). */
+int  dsim_unet_set_sample_size(dsim_unet* h, int side);
+
 /* ---- score tail: replaces diffsim/diffsim.py:177-197 (4x F.scaled_dot_product_attention,
  *      2x F.cosine_similarity or F.mse_loss, mean).  Fused: the O tensors never reach HBM. --
  *   q,k,v       : dtype [n_feat][B][N][H*D]   (features of n_feat images, B = CFG batch = 2)
@@ -150,6 +161,13 @@ int    dsim_pair_score(const void* q, const void* k, const void* v, const int32_
                        const int32_t* idx_b, int n_pairs, int B, int H, int N, int D, int dtype,
                        int similarity, float* out_scores, void* workspace, size_t workspace_bytes,
                        void* stream);
+/* The same call with a per-pair status: status[p] = 0 when score p is finite, 1 when it is NaN or infinite
+ * (non-finite features: an overflowed activation or a corrupt weight; the reference would print the NaN and
+ * count the triplet as wrong, cute_main.py:201-205).  status: device int32 [n_pairs]. */
+int    dsim_pair_score_status(const void* q, const void* k, const void* v, const int32_t* idx_a,
+                              const int32_t* idx_b, int n_pairs, int B, int H, int N, int D, int dtype,
+                              int similarity, float* out_scores, int32_t* status, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* ---- VAE encoder: replaces `pipe.vae.encode(image)` in
  *      DiffSim.prepare_image_latents (diffsim/diffsim.py:92-96).  Sampling

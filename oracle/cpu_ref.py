@@ -143,6 +143,15 @@ def add_noise(x0: torch.Tensor, noise: torch.Tensor, t: int) -> torch.Tensor:
     return a * x0 + b * noise
 
 
+def add_noise_f16(x0: torch.Tensor, noise: torch.Tensor, t: int) -> torch.Tensor:
+    """PNDMScheduler.add_noise as the reference's fp16 pipeline runs it (diffsim_pipeline.py:177-183 on fp16
+    latents): alphas_cumprod is cast to the sample dtype FIRST, the square roots, both products and the sum are
+    fp16 operations.  Returns the fp16 result upcast (the oracle U-Net is fp32).  Pinned by fixture g10."""
+    ac = alphas_cumprod().to(torch.float16)
+    a, b = ac[t] ** 0.5, (1 - ac[t]) ** 0.5
+    return (a * x0.to(torch.float16) + b * noise.to(torch.float16)).float()
+
+
 def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
     """diffusers ``Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)``."""
     half = dim // 2
@@ -613,19 +622,19 @@ def pair_score(qa, ka, va, qb, kb, vb, similarity: str = "cosine") -> torch.Tens
 # ----------------------------------------------------------------------------------------------
 @torch.no_grad()
 def features(unet: UNet2DConditionModel, z0, noise, ctx, target_step=600, target_block="up_blocks",
-             target_layer=0, full=False, stats=None):
+             target_layer=0, full=False, stats=None, fp16_pipeline=False):
     """z0, noise: (1,4,h,w); ctx: (2,L,Dc) = [uncond, cond] -> q,k,v each (2,H,N,D)."""
     t = timestep_from_index(target_step)
-    xt = add_noise(z0, noise, t)
+    xt = add_noise_f16(z0, noise, t) if fp16_pipeline else add_noise(z0, noise, t)
     xin = torch.cat([xt] * 2)          # CFG duplicate (diffsim_pipeline.py:208); PNDM scale = id
     return unet.qkv_at_tap(xin, t, ctx, target_block, target_layer, full=full, stats=stats)
 
 
 @torch.no_grad()
 def diffsim_latents(unet, zA, zB, nA, nB, ctx, target_step=600, target_block="up_blocks",
-                    target_layer=0, similarity="cosine", full=False) -> torch.Tensor:
-    qa, ka, va = features(unet, zA, nA, ctx, target_step, target_block, target_layer, full)
-    qb, kb, vb = features(unet, zB, nB, ctx, target_step, target_block, target_layer, full)
+                    target_layer=0, similarity="cosine", full=False, fp16_pipeline=False) -> torch.Tensor:
+    qa, ka, va = features(unet, zA, nA, ctx, target_step, target_block, target_layer, full, fp16_pipeline=fp16_pipeline)
+    qb, kb, vb = features(unet, zB, nB, ctx, target_step, target_block, target_layer, full, fp16_pipeline=fp16_pipeline)
     return pair_score(qa, ka, va, qb, kb, vb, similarity)
 
 
@@ -798,15 +807,30 @@ def sdxl_inputs(z0: torch.Tensor, noise: torch.Tensor, target_step: int):
     return x / ((s * s + 1) ** 0.5), t
 
 
+def sdxl_inputs_f16(z0: torch.Tensor, noise: torch.Tensor, target_step: int):
+    """The same chain on fp16 tensors, as the reference's fp16 pipeline runs it: prepare_latents multiplies the fp16
+    latents by the python float init_noise_sigma; add_noise casts the sigma table to fp16; scale_model_input divides
+    by a 0-dim fp32 tensor (the fp16 sample keeps its dtype).  Pinned by fixture g10."""
+    ts, sig, init = euler_tables()
+    t = float(ts[target_step])
+    sg = torch.tensor(float(sig[target_step]), dtype=torch.float32)
+    x = z0.to(torch.float16) * init
+    x = x + noise.to(torch.float16) * sg.to(torch.float16)
+    x = x / ((sg ** 2 + 1) ** 0.5)
+    return x.float(), t
+
+
 def sdxl_time_ids(cfg: UNetConfig) -> torch.Tensor:
     side = float(cfg.sample_size * 8)      # height/width default to sample_size * vae_scale_factor
     return torch.tensor([[side, side, 0.0, 0.0, side, side]], dtype=torch.float32)
 
 
 @torch.no_grad()
-def features_xl(unet: UNet2DConditionModel, z0, noise, ctx, pooled, target_step, target_block, target_layer, full=False):
-    """z0, noise (1,4,h,w); ctx (2,L,Dc) = [neg, pos]; pooled (2,P) = [neg, pos] -> q,k,v (2,H,N,D)."""
-    x, t = sdxl_inputs(z0, noise, target_step)
+def features_xl(unet: UNet2DConditionModel, z0, noise, ctx, pooled, target_step, target_block, target_layer, full=False,
+                fp16_pipeline=False):
+    """z0, noise (1,4,h,w) at ANY latent side (time_ids stay the model's native size); ctx (2,L,Dc) = [neg, pos];
+    pooled (2,P) = [neg, pos] -> q,k,v (2,H,N,D)."""
+    x, t = sdxl_inputs_f16(z0, noise, target_step) if fp16_pipeline else sdxl_inputs(z0, noise, target_step)
     xin = torch.cat([x] * 2)
     added = {"text_embeds": pooled, "time_ids": sdxl_time_ids(unet.cfg).repeat(2, 1)}
     return unet.qkv_at_tap(xin, t, ctx, target_block, target_layer, full=full, added_cond_kwargs=added)
@@ -814,9 +838,9 @@ def features_xl(unet: UNet2DConditionModel, z0, noise, ctx, pooled, target_step,
 
 @torch.no_grad()
 def diffsim_xl_latents(unet, zA, zB, nA, nB, ctx, pooled, target_step, target_block, target_layer,
-                       similarity="cosine", full=False):
-    a = features_xl(unet, zA, nA, ctx, pooled, target_step, target_block, target_layer, full)
-    b = features_xl(unet, zB, nB, ctx, pooled, target_step, target_block, target_layer, full)
+                       similarity="cosine", full=False, fp16_pipeline=False):
+    a = features_xl(unet, zA, nA, ctx, pooled, target_step, target_block, target_layer, full, fp16_pipeline)
+    b = features_xl(unet, zB, nB, ctx, pooled, target_step, target_block, target_layer, full, fp16_pipeline)
     return pair_score(*a, *b, similarity)
 
 

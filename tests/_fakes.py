@@ -21,4 +21,20 @@ class FakeVAE:
         class _D:
             def sample(self, generator=None):
                 return mean + (0.1 / 0.18215) * torch.randn(mean.shape, generator=generator)
-        return types.SimpleNamespace(latent_dist=_D())
+        return types.SimpleNamespace(latent_dist=_D(), mean=mean)
+
+
+class FakeVAE16(FakeVAE):
+    """The same stand-in as an fp16 module (the reference's SD1.5 VAE runs in fp16, diffsim/diffsim.py:93): the moments
+    come out in fp16 and ``sample`` draws ``randn_tensor(dtype=float16)`` and does its arithmetic in fp16, as
+    diffusers' DiagonalGaussianDistribution does for fp16 parameters."""
+
+    def encode(self, x):
+        base = FakeVAE.encode(self, x)
+        mean = base.mean.to(torch.float16)
+        std = torch.tensor(0.1 / 0.18215, dtype=torch.float16)
+
+        class _D:
+            def sample(self, generator=None):
+                return mean + std * torch.randn(mean.shape, generator=generator, dtype=torch.float16)
+        return types.SimpleNamespace(latent_dist=_D(), mean=mean)

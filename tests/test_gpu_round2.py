@@ -1,0 +1,198 @@
+"""Round-2 features of the engine, through the C ABI: one weight copy for every tap, run-time latent size, the
+per-pair NaN guard, the reference's fp16 pipeline mode and SDXL away from its native size (fixture g10), the CLIP text
+encoder on the device, and the command-line driver end to end."""
+import ast
+import csv
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from diffsim_amd import config as C
+from diffsim_amd import synth as S
+
+REL_F32 = 1e-4
+
+
+def _rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-6)
+
+
+def _ds(cfg, sd, dtype, **kw):
+    from diffsim_amd.diffsim import DiffSim
+    return DiffSim(torch_dtype=dtype, device="cuda", unet_config=cfg, state_dict=sd, **kw)
+
+
+def test_one_weight_copy_serves_every_tap():
+    """dsim_unet_set_tap: alternating taps on ONE handle gives bit-identical scores to one fresh handle per tap."""
+    sd = S.make_state_dict(C.TINY, seed=0)
+    ctx = S.make_context(C.TINY)
+    zA, zB = S.make_pair_latents(C.TINY, 1)
+    n = S.draw_pair_noise(2334, zA.shape)
+    taps = [("up_blocks", 0, 600), ("down_blocks", 1, 750), ("mid_blocks", 0, 900), ("up_blocks", 2, 600), ("up_blocks", 0, 600)]
+    shared = _ds(C.TINY, sd, torch.bfloat16)
+    got = [shared.diffsim_latents(zA, zB, n[2], n[3], ctx, b, l, st) for b, l, st in taps]
+    assert shared._base is not None and len({id(v._base) for v in shared._engines.values()}) == 1
+    for (b, l, st), g in zip(taps, got):
+        fresh = _ds(C.TINY, sd, torch.bfloat16).diffsim_latents(zA, zB, n[2], n[3], ctx, b, l, st)
+        assert torch.equal(g, fresh), (b, l)
+    # a tap whose weights were never loaded is refused loudly and the handle keeps working at the old tap
+    from diffsim_amd import _lib
+    part = {k: v for k, v in sd.items() if not k.startswith(("up_blocks.2", "up_blocks.3"))}
+    ds = _ds(C.TINY, part, torch.float32)
+    s0 = ds.diffsim_latents(zA, zB, n[2], n[3], ctx, "up_blocks", 0, 600)
+    with pytest.raises(_lib.DsimError):
+        ds.diffsim_latents(zA, zB, n[2], n[3], ctx, "up_blocks", 2, 600)
+    assert torch.equal(ds.diffsim_latents(zA, zB, n[2], n[3], ctx, "up_blocks", 0, 600), s0)
+
+
+def test_latent_size_is_a_runtime_property():
+    """--image_size is free in the reference (argprocess.py:8): the SD1.5 channel plan built with sample_size 8 scores
+    16 x 16 and 24 x 24 latents (ragged 576-token attention tiles) like the oracle."""
+    from oracle import cpu_ref as R
+    cfg = C.SD15_SMALL
+    shapes = C.unet_param_shapes(cfg)
+    sd = S.make_state_dict(cfg, seed=0, keys=[k for k in shapes if not k.startswith(("up_blocks.2", "up_blocks.3", "conv_norm_out", "conv_out"))])
+    full = {k: (sd[k] if k in sd else torch.zeros(s)) for k, s in shapes.items()}
+    unet = R.build_unet(R.UNetConfig(sample_size=8), full)
+    ctx = S.make_context(cfg)
+    ds = _ds(cfg, sd, torch.float32)
+    for side in (16, 24, 8):
+        g = torch.Generator("cpu").manual_seed(side)
+        zA, zB = torch.randn((1, 4, side, side), generator=g), torch.randn((1, 4, side, side), generator=g)
+        n = S.draw_pair_noise(2334, zA.shape)
+        so = float(R.diffsim_latents(unet, zA, zB, n[2], n[3], ctx))
+        s = float(ds.diffsim_latents(zA, zB, n[2], n[3], ctx).cpu())
+        assert _rel(s, so) <= REL_F32, (side, s, so)
+    assert ds.engine("up_blocks", 0).tokens == (8 // 4) ** 2
+
+
+def test_nan_guard_reports_per_pair_status():
+    from diffsim_amd.engine import pair_score
+    g = torch.Generator("cpu").manual_seed(0)
+    q, k, v = (torch.randn((4, 2, 64, 4 * 32), generator=g).cuda().to(torch.bfloat16) for _ in range(3))
+    k[2, 1, 5, 7] = float("nan")                       # image 2 carries one corrupt feature
+    ia = torch.tensor([0, 0, 2, 1], dtype=torch.int32, device="cuda")
+    ib = torch.tensor([1, 2, 3, 3], dtype=torch.int32, device="cuda")
+    for sim in ("cosine", "mse"):
+        s, st = pair_score(q, k, v, ia, ib, 4, sim, return_status=True)
+        assert st.tolist() == [0, 1, 1, 0], (sim, st.tolist())
+        assert torch.isfinite(s[[0, 3]]).all() and not torch.isfinite(s[[1, 2]]).any()
+        assert torch.equal(s[[0, 3]], pair_score(q, k, v, ia, ib, 4, sim)[[0, 3]])
+
+
+def test_g10_fp16_pipeline_mode_and_sdxl_sizes(golden_dir):
+    """noise_dtype=float16 reproduces the reference's fp16 pipeline (fp16 generator draws -- a different random stream --
+    fp16 VAE sample, fp16 add_noise / scale_model_input); SDXL at 64 px keeps the native-size time_ids.  Golden g10 was
+    produced by the reference's own diffsim.py / diffsim_pipeline.py / diffsim_xl*.py (tests/golden/make_golden_fp16.py)."""
+    from diffsim_amd.diffsim_xl import diffsim_xl
+    from tests._fakes import FakeVAE, FakeVAE16
+    g = np.load(os.path.join(golden_dir, "g10_fp16_and_sizes.npz"))
+    img_a, img_b = os.path.join(golden_dir, "g1_img_c.png"), os.path.join(golden_dir, "g1_img_d.png")
+    sd = S.make_state_dict(C.TINY, seed=0)
+    ctx = S.make_context(C.TINY)
+    ds = _ds(C.TINY, sd, torch.float32, vae=FakeVAE16(), encode_prompt=lambda p: ctx, noise_dtype=torch.float16)
+    ds32 = _ds(C.TINY, sd, torch.float32, vae=FakeVAE(), encode_prompt=lambda p: ctx)
+    zA, zB, nA, nB = (torch.from_numpy(g[k]) for k in ("sd15_latA", "sd15_latB", "sd15_noiseA", "sd15_noiseB"))
+    for ci in range(2):
+        blk, layer, step, sim = (str(x) for x in g[f"sd15_case_{ci}"])
+        layer, step, want = ast.literal_eval(layer), int(step), float(g[f"sd15_score_{ci}"][0])
+        s = float(ds.diffsim(img_a, img_b, 128, "The photo of a cat", blk, layer, step, seed=2334, similarity=sim).cpu())
+        assert _rel(s, want) <= REL_F32, (ci, s, want)
+        s_lat = float(ds.diffsim_latents(zA, zB, nA, nB, ctx, blk, layer, step, sim).cpu())
+        assert _rel(s_lat, want) <= REL_F32, (ci, s_lat, want)
+        s32 = float(ds32.diffsim(img_a, img_b, 128, "The photo of a cat", blk, layer, step, seed=2334, similarity=sim).cpu())
+        assert _rel(s32, want) > 1e-3               # the fp32 pipeline is a different run (different noise), not a rounding of this one
+    xsd = S.make_state_dict(C.SDXL_TINY, seed=0)
+    xctx, pooled = S.make_context(C.SDXL_TINY), S.make_pooled(C.SDXL_TINY)
+    xl = {fp16: diffsim_xl(torch.float32, "cuda", unet_config=C.SDXL_TINY, state_dict=xsd, vae=FakeVAE(),
+                           encode_prompt=lambda p: (xctx, pooled), noise_dtype=torch.float16 if fp16 else torch.float32)
+          for fp16 in (False, True)}
+    for ci in range(5):
+        fp16, size, blk, tl, step, sim = (str(x) for x in g[f"xl_case_{ci}"])
+        want = float(g[f"xl_score_{ci}"][0])
+        s = xl[bool(int(fp16))].diffsim_score(img_a, img_b, int(size), "a cat", blk, ast.literal_eval(tl), int(step), sim, 2334)
+        assert s.shape == (1,) and _rel(float(s.cpu()), want) <= REL_F32, (ci, float(s.cpu()), want)
+
+
+def test_text_encoder_on_the_device():
+    """SURVEY 8f #3 on the ROCm device: same numbers as the CPU evaluation (which tests/test_text_encoder.py pins
+    against transformers), for NIGHTS-style per-row prompts; CLIP-L size timed."""
+    import time
+    from diffsim_amd import text as T
+    for cfg in (T.CLIP_TINY, T.CLIP_L):
+        g = torch.Generator().manual_seed(1)
+        sd = {k: (0.02 * torch.randn(s, generator=g) if len(s) > 1 else (1.0 + 0.02 * torch.randn(s, generator=g) if "norm" in k and k.endswith("weight")
+                                                                         else 0.02 * torch.randn(s, generator=g)))
+              for k, s in T.clip_text_param_shapes(cfg).items()}
+        cpu, dev = T.CLIPTextEncoder(cfg, sd, device="cpu"), T.CLIPTextEncoder(cfg, sd, device="cuda")
+        ids = torch.randint(3, cfg.vocab_size - 1, (8, 77), generator=g)
+        for r in range(8):
+            ids[r, 5 + 3 * r:] = cfg.vocab_size - 1             # EOS + padding, different prompt lengths
+        a, b = cpu(ids), dev(ids)
+        for key in ("last_hidden_state", "pooled") + (("text_embeds",) if cfg.projection_dim else ()):
+            err = (a[key] - b[key].cpu()).abs().max().item()
+            assert err <= 2e-4 * max(1.0, float(a[key].abs().max())), (key, err)
+        enc = T.make_encode_prompt(dev, lambda p: ids[hash(p) % 8:hash(p) % 8 + 1])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        outs = [enc(f"An image of a thing {i}") for i in range(32)]          # per-row prompts (night_main.py:67)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 32
+        assert outs[0].shape == (2, 77, cfg.hidden_size) and outs[0].is_cuda
+        print(f"CLIP text encoder {cfg.hidden_size}x{cfg.num_layers}: {1e3 * dt:.2f} ms per prompt on the device")
+
+
+def test_cli_end_to_end(tmp_path, golden_dir, capsys, monkeypatch):
+    """python -m diffsim_amd on a synthetic diffusers-layout checkpoint and synthetic CUTE / NIGHTS trees: the printed
+    accuracies equal the ones computed from pairwise scorer calls, as the reference's loops make them."""
+    from diffsim_amd import cli, loader
+    from tests.test_cli import _write_checkpoint
+    ck = os.path.join(tmp_path, "ckpt"); os.makedirs(ck)
+    _write_checkpoint(ck)
+    monkeypatch.setattr(loader.LazyTokenizer, "__call__",
+                        lambda self, p: torch.tensor([[0] + [3 + (ord(c) % 900) for c in p][:75] + [999] * (76 - min(75, len(p)))]))
+    names = ["g1_img_a.png", "g1_img_b.png", "g1_img_c.png", "g1_img_d.png"]
+    # NIGHTS
+    nd = os.path.join(tmp_path, "nights"); os.makedirs(nd)
+    for n in names:
+        shutil.copy(os.path.join(golden_dir, n), os.path.join(nd, n))
+    rows = [("val", names[0], names[1], names[2], 1, "Cat"), ("val", names[3], names[0], names[1], 0, "Dog"),
+            ("test", names[1], names[2], names[3], 0, "Dog"), ("val", names[2], names[3], names[0], 1, "Cat")]
+    with open(os.path.join(nd, "data.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["split", "ref_path", "left_path", "right_path", "left_vote", "prompt"])
+        w.writerows(rows)
+    base = ["--metric", "diffsim", "--model_path", ck, "--image_size", "128", "--target_block", "up_blocks", "--target_layer", "0",
+            "--target_step", "600", "--similarity", "cosine", "--seed", "2334", "--dtype", "fp32", "--batch", "2"]
+    assert cli.main(base + ["--dataset", "nights", "--image_path", nd]) == 0
+    out = capsys.readouterr().out
+    acc = float(out.split("Final validation accuracy:")[1].split("%")[0])
+    ds = loader.load_diffsim(ck, "fp32", "cuda")
+    correct, val = 0, [r for r in rows if r[0] == "val"]
+    for _, ref, left, right, vote, prompt in val:
+        p = f"An image of a {prompt.lower()}"
+        ab = ds.diffsim(os.path.join(nd, ref), os.path.join(nd, left), 128, p, "up_blocks", [0], 600, seed=2334, similarity="cosine")
+        ac = ds.diffsim(os.path.join(nd, ref), os.path.join(nd, right), 128, p, "up_blocks", [0], 600, seed=2334, similarity="cosine")
+        correct += int((1 if ab > ac else 0) == vote)
+    assert abs(acc - 100.0 * correct / len(val)) < 0.01
+    # CUTE
+    cd = os.path.join(tmp_path, "cute")
+    for inst in range(2):
+        for light in range(2):
+            d = os.path.join(cd, "toy", f"inst{inst}", f"light{light}"); os.makedirs(d)
+            for j, n in enumerate(names[:3]):
+                shutil.copy(os.path.join(golden_dir, names[(j + inst + light) % 4]), os.path.join(d, f"im{j}.png"))
+    assert cli.main(base + ["--dataset", "cute", "--image_path", cd]) == 0
+    out = capsys.readouterr().out
+    trip = cli.cute_triplets(cd, 2334)
+    assert f"Total comparisons: {len(trip)}" in out and len(trip) == 20
+    c1 = 0
+    for a, b, c, prompt in trip:
+        ab = ds.diffsim(a, b, 128, prompt, "up_blocks", [0], 600, seed=2334, similarity="cosine")
+        ac = ds.diffsim(a, c, 128, prompt, "up_blocks", [0], 600, seed=2334, similarity="cosine")
+        c1 += int(ab > ac)
+    assert f"Total {len(trip)}; Correct {c1};" in out

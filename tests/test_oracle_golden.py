@@ -198,3 +198,46 @@ def test_g9_dit_reference_model():
     assert sch.dit_timestep_map(600)[400] == g7["dit_map_400"] == R.dit_timestep_map(600)[400] == 667
     assert sch.dit_model_timestep(600) == 667 and len(sch.dit_timestep_map(600)) == g7["dit_map_len"]
     assert sum(int(np.prod(s)) for s in C.dit_param_shapes(C.DIT_XL2).values()) == 672_436_224
+
+
+# ---- g10: the reference as an fp16 pipeline, and SDXL away from its native image size -------------------------------
+def _xl_latents(img_size, noise_dtype):
+    """Latents / noise exactly as diffsim_xl.diffsim_score produces them with the shared fake VAE
+    (diffsim/diffsim_xl.py:58-63, 74-80): fp32 VAE sample * sf -> fp16; noise drawn in `noise_dtype`."""
+    from diffsim_amd.image import load_image, process_image
+    from tests._fakes import FakeVAE
+    g = torch.Generator("cpu").manual_seed(2334)
+    lat = []
+    for name in ("g1_img_c.png", "g1_img_d.png"):
+        t = process_image(load_image(os.path.join(G, name)), img_size)
+        lat.append((FakeVAE.config.scaling_factor * FakeVAE().encode(t.float()).latent_dist.sample(generator=g)).to(torch.float16).float())
+    nA = torch.randn(lat[0].shape, generator=g, dtype=noise_dtype).float()
+    nB = torch.randn(lat[1].shape, generator=g, dtype=noise_dtype).float()
+    return lat[0], lat[1], nA, nB
+
+
+def test_g10_fp16_pipeline_and_sizes(tiny):
+    import ast
+    g = np.load(os.path.join(G, "g10_fp16_and_sizes.npz"))
+    unet, ctx = tiny
+    zA, zB, nA, nB = (torch.from_numpy(g[k]) for k in ("sd15_latA", "sd15_latB", "sd15_noiseA", "sd15_noiseB"))
+    # the fp16 draws are a different stream from the fp32 draws of the same seed (why g5 cannot pin this mode)
+    n32 = R.draw_pair_noise(2334, zA.shape)
+    assert (n32[2] - nA).abs().max() > 1.0
+    ctx16 = ctx.to(torch.float16).float()              # the fp16 pipeline hands the U-Net fp16 prompt embeddings
+    for ci in range(2):
+        blk, layer, step, sim = (str(x) for x in g[f"sd15_case_{ci}"])
+        want = float(g[f"sd15_score_{ci}"][0])
+        so = float(R.diffsim_latents(unet, zA, zB, nA, nB, ctx16, int(step), blk, 0, sim, fp16_pipeline=True))
+        assert abs(so - want) <= 2e-5 * abs(want) + 1e-7, (ci, so, want)
+    sd = S.make_state_dict(C.SDXL_TINY, seed=0)
+    xl = R.build_unet(R.SDXL_TINY, sd)
+    xctx, pooled = S.make_context(C.SDXL_TINY), S.make_pooled(C.SDXL_TINY)
+    for ci in range(5):
+        fp16, size, blk, tl, step, sim = (str(x) for x in g[f"xl_case_{ci}"])
+        fp16, size, tl, step = bool(int(fp16)), int(size), ast.literal_eval(tl), int(step)
+        a, b, nA, nB = _xl_latents(size, torch.float16 if fp16 else torch.float32)
+        c_, p_ = (xctx.to(torch.float16).float(), pooled.to(torch.float16).float()) if fp16 else (xctx, pooled)
+        so = float(R.diffsim_xl_latents(xl, a, b, nA, nB, c_, p_, step, blk, tl, sim, fp16_pipeline=fp16))
+        want = float(g[f"xl_score_{ci}"][0])
+        assert abs(so - want) <= 2e-5 * abs(want) + 1e-7, (ci, so, want)

@@ -23,7 +23,12 @@ class _StandInScorer:
     device = torch.device("cpu")
 
     def score_latent_pairs(self, latA, latB, nA, nB, prompt, **kw):
-        return (latA.flatten(1).sum(1) * 0.5 - latB.flatten(1).mean(1)).float()
+        s = (latA.flatten(1).sum(1) * 0.5 - latB.flatten(1).mean(1)).float()
+        for nz in (nA, nB):
+            if nz is not None:      # shared (1,...) draw or per-pair (n,...) noise, as DiffSim.score_latent_pairs accepts
+                assert nz.shape[0] in (1, latA.shape[0])
+                s = s + nz.expand(latA.shape[0], *nz.shape[1:]).flatten(1).sum(1) * 0.25
+        return s
 
 
 def _worker(rank, world, port, n, q):
@@ -37,7 +42,12 @@ def _worker(rank, world, port, n, q):
         sc = _StandInScorer()
         got = P.score_pairs_sharded(sc, latA, latB, None, None, "p", rank, world)
         want = sc.score_latent_pairs(latA, latB, None, None, "p")
-        q.put((rank, bool(torch.equal(got, want)), P.shard_indices(n, rank, world)))
+        ok = bool(torch.equal(got, want))
+        # per-pair noise must be sharded with the pairs; a shared (1,...) draw is passed through
+        nzA, nzB = torch.randn(n, 4, 4, 4, generator=g), torch.randn(1, 4, 4, 4, generator=g)
+        got = P.score_pairs_sharded(sc, latA, latB, nzA, nzB, "p", rank, world)
+        ok = ok and bool(torch.equal(got, sc.score_latent_pairs(latA, latB, nzA, nzB, "p")))
+        q.put((rank, ok, P.shard_indices(n, rank, world)))
     finally:
         dist.destroy_process_group()
 

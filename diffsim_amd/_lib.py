@@ -86,6 +86,9 @@ SYMBOLS = {
     "dsim_dit_finalize": (_i, [_vp, _vp]),
     "dsim_dit_set_conditioning": (_i, [_vp, _i, _i, _i, _vp]),
     "dsim_dit_set_attention": (_i, [_vp, _i]),
+    "dsim_dit_profile": (_i, [_vp, _i]),
+    "dsim_dit_profile_count": (_i, [_vp]),
+    "dsim_dit_profile_get": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dsim_dit_workspace_bytes": (_sz, [_vp, _i]),
     "dsim_dit_qkv": (_i, [_vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dsim_pair_score_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),

@@ -105,7 +105,40 @@ struct DWalk {
         g.epi = residual ? EPI_RESIDUAL : EPI_NONE; g.residual = residual; g.out = out; g.ldo = N;
         g.zero_page = h->zero_page;
         if (!run) return DSIM_OK;
-        return launch_gemm(g, h->dt, s);
+        if (h->profiling) {
+            int bm, bn;
+            gemm_tile_choice(g, &bm, &bn);
+            const bool slow = act != 0 || gate != nullptr;      // the tanh-GELU / adaLN-gate epilogue template (gemm.hip EK_SLOW)
+            if (slow && bm == 256 && bn == 320) bm = 128, bn = 128;
+            pbegin(std::string("gemm_") + dtn() + "_" + std::to_string(bm) + "x" + std::to_string(bn) + "_linear" +
+                       (slow ? "_dit" : (residual ? "_res" : "")) + "|M" + std::to_string(M) + " N" + std::to_string(N) + " K" + std::to_string(K),
+                   2.0 * M * (double)N * K, (double)es() * ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1)));
+        }
+        const int st = launch_gemm(g, h->dt, s);
+        pend();
+        return st;
+    }
+    // per-launch HIP-event brackets of a profiled forward (same record format as the U-Net executor's)
+    const char* dtn() const { return h->dt == DSIM_F32 ? "f32" : "bf16"; }
+    void pbegin(const std::string& name, double flops, double bytes) {
+        if (!run || !h->profiling) return;
+        ProfRec r;
+        r.name = name; r.flops = flops; r.bytes = bytes;
+        (void)hipEventCreate(&r.e0);
+        (void)hipEventCreate(&r.e1);
+        (void)hipEventRecord(r.e0, s);
+        h->prof.push_back(r);
+    }
+    void pend() {
+        if (!run || !h->profiling) return;
+        (void)hipEventRecord(h->prof.back().e1, s);
+    }
+    int lnmod(const void* x, const float* scale2, const float* shift2, void* out, int M, int D, int T) {
+        if (!run) return DSIM_OK;
+        pbegin(std::string("layernorm_mod_") + dtn() + "|M" + std::to_string(M) + " C" + std::to_string(D), 0.0, 2.0 * M * (double)D * es());
+        const int st = launch_layernorm_mod(x, scale2, shift2, out, M, D, T, 1e-6f, h->dt, s);
+        pend();
+        return st;
     }
 
     int go(const float* lat, const float* noise, float sa, float sb) {
@@ -131,7 +164,7 @@ struct DWalk {
         for (int blk = 0; blk <= c.tap_layer; ++blk) {
             const std::string b = "blocks." + std::to_string(blk) + ".";
             DGET(qw, b + "attn.qkv.weight"); DGET(qb, b + "attn.qkv.bias");
-            if (run) CK(launch_layernorm_mod(x, modv(blk, 1), modv(blk, 0), nb, M, D, T, 1e-6f, h->dt, s));
+            CK(lnmod(x, modv(blk, 1), modv(blk, 0), nb, M, D, T));
             if (blk == c.tap_layer) {
                 // the pre-hook's input is the modulated norm1 output; q/k/v = row blocks of the fused qkv Linear
                 for (int j = 0; j < 3; ++j) {
@@ -151,11 +184,15 @@ struct DWalk {
                 a.q = big; a.ldq = 3 * D;
                 a.k = (char*)big + (size_t)D * es(); a.v = (char*)big + (size_t)2 * D * es(); a.ldk = 3 * D;
                 a.out = ab; a.ldo = D; a.B = n * 2; a.Bkv = n * 2; a.H = H; a.Nq = T; a.Nk = T; a.D = D / H;
-                if (h->attn_mode == 1) CK(launch_attention_fp8(a, s));
-                else CK(launch_attention(a, h->dt, s));
+                pbegin(std::string(h->attn_mode == 1 ? "attention_fp8_d" : "attention_bf16_d") + std::to_string(a.D) + "|B" +
+                           std::to_string(a.B) + " H" + std::to_string(H) + " Nq" + std::to_string(T) + " Nk" + std::to_string(T),
+                       4.0 * a.B * H * (double)T * T * a.D, (double)es() * a.B * H * a.D * 4.0 * T);
+                const int st = h->attn_mode == 1 ? launch_attention_fp8(a, s) : launch_attention(a, h->dt, s);
+                pend();
+                CK(st);
             }
             CK(linear(ab, D, ow->p, (const float*)ob->p, x, M, D, 0, modv(blk, 2), x, T));
-            if (run) CK(launch_layernorm_mod(x, modv(blk, 4), modv(blk, 3), nb, M, D, T, 1e-6f, h->dt, s));
+            CK(lnmod(x, modv(blk, 4), modv(blk, 3), nb, M, D, T));
             CK(linear(nb, D, f1w->p, (const float*)f1b->p, big, M, F, 1, nullptr, nullptr, T));
             CK(linear(big, F, f2w->p, (const float*)f2b->p, x, M, D, 0, modv(blk, 5), x, T));
         }
@@ -260,6 +297,28 @@ int dsim_dit_set_attention(dsim_dit* h, int mode) {
     const int hd = h->cfg.num_heads > 0 ? h->cfg.hidden_size / h->cfg.num_heads : 0;
     if (mode == 1 && (h->dt != DSIM_BF16 || (hd != 72 && hd != 32))) return DSIM_ERR_INVALID;
     h->attn_mode = mode;
+    return DSIM_OK;
+}
+
+int dsim_dit_profile(dsim_dit* h, int enable) {
+    if (!h) return DSIM_ERR_INVALID;
+    h->clear_profile();
+    h->profiling = enable != 0;
+    return DSIM_OK;
+}
+
+int dsim_dit_profile_count(const dsim_dit* h) { return h ? (int)h->prof.size() : 0; }
+
+int dsim_dit_profile_get(dsim_dit* h, int i, char* name, int name_cap, double* flops, double* bytes, double* ms) {
+    if (!h || i < 0 || i >= (int)h->prof.size() || !name || name_cap < 2 || !flops || !bytes || !ms) return DSIM_ERR_INVALID;
+    ProfRec& r = h->prof[i];
+    if (r.e0 && r.e1) {
+        DSIM_HIP_CHECK(hipEventSynchronize(r.e1));
+        DSIM_HIP_CHECK(hipEventElapsedTime(&r.ms, r.e0, r.e1));
+    }
+    strncpy(name, r.name.c_str(), (size_t)name_cap - 1);
+    name[name_cap - 1] = 0;
+    *flops = r.flops; *bytes = r.bytes; *ms = (double)r.ms;
     return DSIM_OK;
 }
 

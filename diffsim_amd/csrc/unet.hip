@@ -84,7 +84,8 @@ struct Walk {
                                    (g.epi == EPI_GEGLU ? "_geglu" : (g.epi == EPI_RESIDUAL ? "_res" : ""));   // one family per kernel symbol
             const double e = (double)es();
             const double outc = g.epi == EPI_GEGLU ? g.N / 2 : g.N;
-            pbegin(nm, 2.0 * g.M * (double)g.N * g.K,
+            pbegin(nm + "|M" + std::to_string(g.M) + " N" + std::to_string(g.N) + " K" + std::to_string(g.K),
+                   2.0 * g.M * (double)g.N * g.K,
                    e * ((double)g.M * (g.mode == GEMM_CONV3 ? g.C0 : g.K) + (double)g.N * g.K +
                         (double)g.M * outc * (g.residual ? 2 : 1)));
         }
@@ -121,7 +122,8 @@ struct Walk {
     int gn(const Act& x0, const Act* x1, const Packed* g, const Packed* b, void* out, float eps, int silu) {
         if (!run) return DSIM_OK;
         const double n = (double)B2 * x0.H * x0.W * (x0.C + (x1 ? x1->C : 0));
-        pbegin(std::string("groupnorm_") + dtn(), 0.0, 3.0 * n * es());      // read (stats) + read + write
+        pbegin(std::string("groupnorm_") + dtn() + "|B" + std::to_string(B2) + " HW" + std::to_string(x0.H * x0.W) + " C" +
+                   std::to_string(x0.C + (x1 ? x1->C : 0)), 0.0, 3.0 * n * es());      // read (stats) + read + write
         const int st = launch_groupnorm(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, (const float*)g->p,
                                         (const float*)b->p, out, B2, x0.H * x0.W, h->cfg.norm_num_groups, eps, silu,
                                         h->dt, gn_scratch, s);
@@ -130,14 +132,15 @@ struct Walk {
     }
     int ln(const void* x, const Packed* g, const Packed* b, void* out, int M, int C) {
         if (!run) return DSIM_OK;
-        pbegin(std::string("layernorm_") + dtn(), 0.0, 2.0 * M * (double)C * es());
+        pbegin(std::string("layernorm_") + dtn() + "|M" + std::to_string(M) + " C" + std::to_string(C), 0.0, 2.0 * M * (double)C * es());
         const int st = launch_layernorm(x, (const float*)g->p, (const float*)b->p, out, M, C, 1e-5f, h->dt, s);
         pend();
         return st;
     }
     int attn(const AttnArgs& a) {
         if (!run) return DSIM_OK;
-        pbegin(std::string("attention_") + dtn() + "_d" + std::to_string(a.D),
+        pbegin(std::string("attention_") + dtn() + "_d" + std::to_string(a.D) + "|B" + std::to_string(a.B) + " H" + std::to_string(a.H) +
+                   " Nq" + std::to_string(a.Nq) + " Nk" + std::to_string(a.Nk),
                4.0 * a.B * a.H * (double)a.Nq * a.Nk * a.D,
                (double)es() * a.B * a.H * a.D * (2.0 * a.Nq + 2.0 * a.Nk));
         const int st = launch_attention(a, h->dt, s);

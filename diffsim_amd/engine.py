@@ -180,17 +180,18 @@ class UNetEngine:
         self._profiling = bool(enable)
         _lib.check(self.L.dsim_unet_profile(self._h, int(enable)), "profile")
 
-    def profile_records(self):
+    def profile_records(self, detail: bool = False):
         """[(kernel family, algorithmic flops, algorithmic bytes, ms)] of the forwards run since
-        profile(True); synchronises the device first."""
+        profile(True); synchronises the device first.  detail=True appends the launch's shape string."""
         torch.cuda.synchronize(self.device)
         out = []
-        buf = C.create_string_buffer(128)
+        buf = C.create_string_buffer(160)
         fl, by, ms = C.c_double(), C.c_double(), C.c_double()
         for i in range(self.L.dsim_unet_profile_count(self._h)):
-            _lib.check(self.L.dsim_unet_profile_get(self._h, i, buf, 128, C.byref(fl), C.byref(by), C.byref(ms)),
+            _lib.check(self.L.dsim_unet_profile_get(self._h, i, buf, 160, C.byref(fl), C.byref(by), C.byref(ms)),
                        "profile_get")
-            out.append((buf.value.decode(), fl.value, by.value, ms.value))
+            fam, _, shape = buf.value.decode().partition("|")
+            out.append((fam, fl.value, by.value, ms.value, shape) if detail else (fam, fl.value, by.value, ms.value))
         return out
 
     def workspace_bytes(self, n_images: int) -> int:
@@ -544,6 +545,21 @@ class DiTEngine:
                 self._h = C.c_void_p()
         except Exception:
             pass
+
+    def profile(self, enable: bool):
+        _lib.check(self.L.dsim_dit_profile(self._h, int(enable)), "dit profile")
+
+    def profile_records(self, detail: bool = False):
+        """Same records as UNetEngine.profile_records."""
+        torch.cuda.synchronize(self.device)
+        out = []
+        buf = C.create_string_buffer(160)
+        fl, by, ms = C.c_double(), C.c_double(), C.c_double()
+        for i in range(self.L.dsim_dit_profile_count(self._h)):
+            _lib.check(self.L.dsim_dit_profile_get(self._h, i, buf, 160, C.byref(fl), C.byref(by), C.byref(ms)), "dit profile_get")
+            fam, _, shape = buf.value.decode().partition("|")
+            out.append((fam, fl.value, by.value, ms.value, shape) if detail else (fam, fl.value, by.value, ms.value))
+        return out
 
     def set_conditioning(self, t_model: int, y0: int, y1: int):
         if self._cond != (t_model, y0, y1):

@@ -140,6 +140,9 @@ def load_diffsim(model_path: str, dtype: str = "bf16", device: str = "cuda", noi
     te_dir = os.path.join(model_path, "text_encoder")
     tcfg = clip_config_from_json(_json(te_dir), T.CLIP_L)
     te_sd = load_state_dict(te_dir)
+    if tcfg.hidden_size != ucfg.cross_attention_dim:
+        raise ValueError(f"text encoder width {tcfg.hidden_size} != unet cross_attention_dim {ucfg.cross_attention_dim}")
+    ucfg = dataclasses.replace(ucfg, ctx_len=tcfg.max_positions)       # context length = the text encoder's positions (77)
     vae = VAEEncoder(vcfg, vae_sd, td, dev)                    # first GPU touch: raises DsimError without a GPU
     enc = T.CLIPTextEncoder(tcfg, te_sd, device=dev, dtype=torch.float32)
     encode = T.make_encode_prompt(enc, LazyTokenizer(os.path.join(model_path, "tokenizer"), tcfg.max_positions))

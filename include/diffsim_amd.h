@@ -228,6 +228,10 @@ int    dsim_dit_set_conditioning(dsim_dit* h, int t_model, int y0, int y1, void*
  * reference's timm Attention (DiT/modelsdit.py:103-124, F.scaled_dot_product_attention in fp16) has no such mode:
  * it is an opt-in accuracy/throughput trade, compared with the oracle under a stated looser tolerance. */
 int    dsim_dit_set_attention(dsim_dit* h, int mode);
+/* Measurement aid, same contract and record format as dsim_unet_profile / _count / _get */
+int    dsim_dit_profile(dsim_dit* h, int enable);
+int    dsim_dit_profile_count(const dsim_dit* h);
+int    dsim_dit_profile_get(dsim_dit* h, int i, char* name, int name_cap, double* flops, double* bytes, double* ms);
 size_t dsim_dit_workspace_bytes(const dsim_dit* h, int n_images);
 /* x_t = sqrt_abar*latents + sqrt_1m_abar*noise (DDIM add_noise at t = target_step, diffsim_dit.py:63-72);
  * q,k,v (out): compute dtype [n_images][2][tokens][heads*head_dim] */

@@ -543,12 +543,13 @@ class UNet2DConditionModel(nn.Module):
     def forward(self, sample, t, ctx, stats: Optional[dict] = None, added_cond_kwargs: Optional[dict] = None):
         """Full forward to ``conv_out`` (what diffsim_pipeline.py:213-221 executes)."""
         b = sample.shape[0]
+        wd = self.conv_in.weight.dtype        # float32; float64 when the oracle is evaluated in double (tools/sdxl_f64_probe.py)
         tt = torch.full((b,), float(t), dtype=torch.float32)
-        temb = self.time_embedding(timestep_embedding(tt, self.cfg.block_out_channels[0]))
+        temb = self.time_embedding(timestep_embedding(tt, self.cfg.block_out_channels[0]).to(wd))
         if self.cfg.addition_embed:
             te, ids = added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]
             tid = timestep_embedding(ids.flatten().float(), self.cfg.addition_time_embed_dim).reshape(b, -1)
-            temb = temb + self.add_embedding(torch.cat([te.float(), tid], dim=-1))
+            temb = temb + self.add_embedding(torch.cat([te.to(wd), tid.to(wd)], dim=-1))
         h = self.conv_in(sample)
         skips = (h,)
         _rec(stats, "conv_in", h)

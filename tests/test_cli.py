@@ -54,7 +54,9 @@ def test_cute_triplet_walk(tmp_path):
 
 def _write_checkpoint(root):
     from safetensors.torch import save_file
-    ucfg, vcfg, tcfg = C.TINY, C.VAE_TINY, T.CLIP_TINY
+    import dataclasses
+    # the text encoder's width is the U-Net's cross_attention_dim, its 77 positions the context length
+    ucfg, vcfg, tcfg = C.TINY, C.VAE_TINY, dataclasses.replace(T.CLIP_TINY, hidden_size=C.TINY.cross_attention_dim, projection_dim=0)
     os.makedirs(os.path.join(root, "unet")); os.makedirs(os.path.join(root, "vae")); os.makedirs(os.path.join(root, "text_encoder"))
     save_file(S.make_state_dict(ucfg, seed=0), os.path.join(root, "unet", "diffusion_pytorch_model.safetensors"))
     json.dump({"in_channels": 4, "out_channels": 4, "block_out_channels": list(ucfg.block_out_channels),
@@ -82,7 +84,7 @@ def test_loader_parses_diffusers_layout(tmp_path):
     assert {k: tuple(v.shape) for k, v in sd.items()} == C.unet_param_shapes(C.TINY)
     assert loader.vae_config_from_json(loader._json(os.path.join(tmp_path, "vae"))) == C.VAE_TINY
     tc = loader.clip_config_from_json(loader._json(os.path.join(tmp_path, "text_encoder")), T.CLIP_L)
-    assert (tc.hidden_size, tc.num_layers, tc.num_heads, tc.vocab_size) == (64, 2, 4, 1000)
+    assert (tc.hidden_size, tc.num_layers, tc.num_heads, tc.vocab_size) == (128, 2, 4, 1000)
     # SDXL's config.json idioms: per-level head counts / transformer depths, text_time conditioning
     xl = loader.unet_config_from_json({"block_out_channels": [320, 640, 1280], "down_block_types": list(C.SDXL.down_block_types),
                                        "up_block_types": list(C.SDXL.up_block_types), "attention_head_dim": [5, 10, 20],

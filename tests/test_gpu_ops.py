@@ -133,7 +133,11 @@ def test_layernorm(eng, dtype, M, C):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,Bkv,H,Nq,Nk,D", [
     (2, 2, 8, 256, 256, 160), (2, 2, 8, 1024, 1024, 80), (2, 2, 8, 4096, 4096, 40), (4, 2, 8, 256, 77, 160),
-    (2, 2, 4, 64, 64, 16), (2, 2, 4, 16, 13, 64), (3, 3, 2, 100, 70, 32), (2, 2, 8, 64, 64, 160), (2, 1, 16, 256, 256, 72)])
+    (2, 2, 4, 64, 64, 16), (2, 2, 4, 16, 13, 64), (3, 3, 2, 100, 70, 32), (2, 2, 8, 64, 64, 160), (2, 1, 16, 256, 256, 72),
+    # ragged key counts around the 32-key MFMA blocks and the 64-key tiles for every production head dim, the 77-key
+    # cross-attention shapes, a single tile, many tiles
+    (2, 2, 8, 300, 77, 40), (4, 2, 5, 200, 77, 64), (2, 2, 4, 130, 200, 72), (2, 2, 4, 96, 31, 80), (2, 2, 2, 64, 33, 40),
+    (2, 1, 2, 64, 64, 40), (2, 2, 2, 128, 65, 64), (1, 1, 2, 160, 97, 40), (2, 2, 2, 96, 129, 80), (1, 1, 3, 64, 449, 72)])
 def test_attention(eng, dtype, B, Bkv, H, Nq, Nk, D):
     g = torch.Generator().manual_seed(Nq + Nk + D)
     q = torch.randn(B, Nq, H * D, generator=g) * 1.3
@@ -327,7 +331,7 @@ def test_conv3x3_randomized_shapes(eng):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("D,scale", [(40, 3.0), (160, 2.0), (64, 3.0)])
+@pytest.mark.parametrize("D,scale", [(40, 3.0), (160, 2.0), (64, 3.0), (72, 3.0), (80, 3.0)])
 def test_attention_peaked_logits(eng, dtype, D, scale):
     """Near one-hot softmax rows (logit standard deviation 9 = 13 in log2 units, spreads of +-50): the running-max
     re-base path runs on many key tiles and exp2 underflows for most keys -- results must stay finite and match torch.

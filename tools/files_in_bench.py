@@ -1,23 +1,67 @@
-"""Development probe: files-in throughput of DiffSim.score_pairs (PNG decode + Lanczos resize on the host thread pool,
-VAE + U-Net + tail on the GPU), synthetic weights, 64 random 600x500 PNG pairs."""
-import os, sys, time, tempfile
+#!/usr/bin/env python3
+"""Development probe: files-in throughput (PNG decode + Lanczos resize on the host thread pool, VAE + text encoder +
+U-Net + tail on the GPU), synthetic weights, random 600x500 PNGs.  Two legs, one JSON line:
+  pairs     DiffSim.score_pairs over 64 path pairs with one prompt (the CUTE-style call pattern)
+  triplets  harness.score_path_triplets over 48 (ref, left, right, prompt) rows with 12 distinct per-row prompts, each
+            encoded once by the CLIP-L-sized text encoder on the device (the NIGHTS call pattern, night_main.py:59-90)"""
+import json
+import os
+import sys
+import tempfile
+import time
+
 import numpy as np
 import torch
 from PIL import Image
-sys.path.insert(0, "/root/repo")
-from diffsim_amd import config as C, synth as S
-from diffsim_amd.diffsim import DiffSim
-from diffsim_amd.engine import VAEEncoder
 
-d = tempfile.mkdtemp(); rng = np.random.default_rng(0); paths = []
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diffsim_amd import config as C, harness as H, synth as S, text as T        # noqa: E402
+from diffsim_amd.diffsim import DiffSim                                          # noqa: E402
+from diffsim_amd.engine import VAEEncoder                                        # noqa: E402
+
+d = tempfile.mkdtemp()
+rng = np.random.default_rng(0)
+paths = []
 for i in range(32):
-    p = os.path.join(d, f"im{i}.png"); Image.fromarray(rng.integers(0, 255, (500, 600, 3), dtype=np.uint8)).save(p); paths.append(p)
+    p = os.path.join(d, f"im{i}.png")
+    Image.fromarray(rng.integers(0, 255, (500, 600, 3), dtype=np.uint8)).save(p)
+    paths.append(p)
 pairs = [(paths[i % 32], paths[(i * 7 + 3) % 32]) for i in range(64)]
 vae = VAEEncoder(C.VAE_SD15, S.make_state_dict(C.VAE_SD15, seed=1), torch.bfloat16, "cuda")
-ctx = S.make_context(C.SD15)
-ds = DiffSim(torch.bfloat16, "cuda", state_dict=S.make_state_dict(C.SD15, seed=0), vae=vae, encode_prompt=lambda p: ctx)
+g = torch.Generator().manual_seed(1)
+tsd = {k: (0.02 * torch.randn(s, generator=g) if not (k.endswith("weight") and "norm" in k) else 1.0 + 0.02 * torch.randn(s, generator=g))
+       for k, s in T.clip_text_param_shapes(T.CLIP_L).items()}
+enc = T.CLIPTextEncoder(T.CLIP_L, tsd, device="cuda")
+n_enc = [0]
+
+
+def tokenize(p):          # stand-in tokenizer (the CLIP vocabulary files are not available offline): 77 ids, EOS-padded
+    n_enc[0] += 1
+    ids = [49406] + [1000 + (ord(c) * 31) % 40000 for c in p][:75]
+    return torch.tensor([ids + [49407] * (77 - len(ids))])
+
+
+ds = DiffSim(torch.bfloat16, "cuda", state_dict=S.make_state_dict(C.SD15, seed=0), vae=vae,
+             encode_prompt=T.make_encode_prompt(enc, tokenize))
 ds.score_pairs(pairs[:16], 512, "a photo", "up_blocks", 0, 600, seed=2334, batch_pairs=16)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 s = ds.score_pairs(pairs, 512, "a photo", "up_blocks", 0, 600, seed=2334, batch_pairs=16)
-torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(f"files-in: {len(pairs)} pairs in {dt*1e3:.0f} ms -> {len(pairs)/dt:.1f} pairs/s  (host cores {os.cpu_count()})", s[:3].tolist())
+torch.cuda.synchronize(); dt_pairs = time.perf_counter() - t0
+
+trip = [(paths[i % 32], paths[(i * 5 + 1) % 32], paths[(i * 11 + 2) % 32], f"An image of a thing number {i % 12}") for i in range(48)]
+H.score_path_triplets(ds, trip[:12], 512, "up_blocks", [0], 600, 2334, "cosine", batch_triplets=10)
+ds._ctx.clear()
+n_enc[0] = 0
+torch.cuda.synchronize(); t0 = time.perf_counter()
+sl, sr, bad = H.score_path_triplets(ds, trip, 512, "up_blocks", [0], 600, 2334, "cosine", batch_triplets=10)
+torch.cuda.synchronize(); dt_trip = time.perf_counter() - t0
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(20):
+    enc(tokenize(f"prompt {i}"))
+torch.cuda.synchronize(); dt_txt = (time.perf_counter() - t0) / 20
+print(json.dumps({"probe": "files-in (decode + resize + VAE + text + U-Net + tail), SD1.5 512 px, bf16, synthetic weights",
+                  "pairs_per_s_one_prompt": round(len(pairs) / dt_pairs, 1), "pairs": len(pairs),
+                  "triplets_per_s_per_row_prompts": round(len(trip) / dt_trip, 1), "pair_scores_per_s_triplets": round(2 * len(trip) / dt_trip, 1),
+                  "triplets": len(trip), "distinct_prompts": 12, "prompt_encodes": n_enc[0] // 2, "nonfinite_scores": bad,
+                  "clip_l_text_encoder_ms_per_prompt": round(1e3 * dt_txt, 2), "host_cpu_count": os.cpu_count(),
+                  "score_sample": [round(float(x), 5) for x in s[:3]]}))

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): the rocprofv3 passes whose summaries are committed under profiles/.
-#   tools/profile_round.sh <tag>      e.g. r01c  -> gpurun_out/prof_<tag>_{trace,fetch,write,mfma}, gpurun_out/bench_<tag>.json
+#   tools/profile_round.sh <tag>   e.g. r02f -> gpurun_out/prof_<tag>_{trace,fetch,write,mfma,tap1,tap2}, gpurun_out/bench_<tag>*.json
+# PMC passes are separate runs with --pmc only (no trace domains), as the pool requires.
 TAG=$1
 R=$(pwd)
 export TMPDIR=/tmp
@@ -8,6 +9,7 @@ mkdir -p $R/gpurun_out
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_trace -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $R/gpurun_out/bench_${TAG}_under_rocprof.json 2> $R/gpurun_out/rocprof_${TAG}_trace.log
 echo trace rc=$?
+find $R/gpurun_out/prof_${TAG}_trace -type f ! -name "*kernel_stats.csv" -delete
 for c in fetch:FETCH_SIZE write:WRITE_SIZE "mfma:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   name=${c%%:*}; ctr=${c#*:}
   rocprofv3 --pmc $ctr --output-format csv -d $R/gpurun_out/prof_${TAG}_${name} -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > /dev/null 2> $R/gpurun_out/rocprof_${TAG}_${name}.log
@@ -15,7 +17,19 @@ for c in fetch:FETCH_SIZE write:WRITE_SIZE "mfma:SQ_VALU_MFMA_BUSY_CYCLES GRBM_G
   # keep only the counter csv (the merged-back directory is size-limited)
   find $R/gpurun_out/prof_${TAG}_${name} -type f ! -name "*counter_collection.csv" -delete
 done
+# the tap layer alone (north_star MFMA-utilisation target): two SQ passes
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $R/gpurun_out/prof_${TAG}_tap1 -- python3 $R/tools/tap_probe.py > /dev/null 2> $R/gpurun_out/rocprof_${TAG}_tap1.log; echo tap1 rc=$?
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $R/gpurun_out/prof_${TAG}_tap2 -- python3 $R/tools/tap_probe.py > /dev/null 2> $R/gpurun_out/rocprof_${TAG}_tap2.log; echo tap2 rc=$?
+for t in tap1 tap2; do find $R/gpurun_out/prof_${TAG}_$t -type f ! -name "*counter_collection.csv" -delete; done
+# kernel stats of the secondary configs
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_trace_sdxl -- python3 $R/bench.py --model sdxl --batch-pairs 8 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/rocprof_${TAG}_trace_sdxl.log; echo trace_sdxl rc=$?
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_trace_pixels -- python3 $R/bench.py --pixels-in --batch-pairs 16 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/rocprof_${TAG}_trace_pixels.log; echo trace_pixels rc=$?
+for t in trace_sdxl trace_pixels; do find $R/gpurun_out/prof_${TAG}_$t -type f ! -name "*kernel_stats.csv" -delete; done
 cd $R
-python3 bench.py --steps 6 --warmup 2 > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.log
-echo bench rc=$?
-tail -c 600 gpurun_out/bench_${TAG}.json
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.log; echo bench rc=$?
+python3 bench.py --model sdxl --batch-pairs 8 --steps 6 --warmup 2 > gpurun_out/bench_${TAG}_sdxl.json 2> gpurun_out/bench_${TAG}_sdxl.log; echo sdxl rc=$?
+python3 bench.py --model dit --batch-pairs 64 --steps 10 --warmup 3 > gpurun_out/bench_${TAG}_dit.json 2> gpurun_out/bench_${TAG}_dit.log; echo dit rc=$?
+python3 bench.py --model dit --fp8-attention --batch-pairs 64 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_${TAG}_dit_fp8.json 2> gpurun_out/bench_${TAG}_dit_fp8.log; echo ditfp8 rc=$?
+python3 bench.py --pixels-in --batch-pairs 16 --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/bench_${TAG}_pixels_in.json 2> gpurun_out/bench_${TAG}_pixels_in.log; echo pixels rc=$?
+python3 tools/files_in_bench.py > gpurun_out/bench_${TAG}_files_in.json 2> gpurun_out/bench_${TAG}_files_in.log; echo files_in rc=$?
+tail -c 400 gpurun_out/bench_${TAG}.json

@@ -88,6 +88,7 @@ int convert_f32_to(const float* src, void* dst, int dtype, size_t n, hipStream_t
 
 // norms -- norm.hip
 size_t groupnorm_scratch_bytes(int B, int groups);
+int groupnorm_passes(int C0, int C1, int HW, int groups, int dtype);    // 2 (one-pass form) or 3: algorithmic tensor passes
 int launch_groupnorm(const void* x0, int C0, const void* x1, int C1, const float* gamma,
                      const float* beta, void* out, int B, int HW, int groups, float eps, int silu,
                      int dtype, void* scratch, hipStream_t s);

@@ -12,9 +12,13 @@
 //   2. gn_apply : folds the slab partials in fixed order, then y = (x-mean)*rstd*gamma+beta
 //                 [*sigmoid] with 16-byte loads and stores.
 // No float atomics anywhere: results are bit-reproducible and independent of batch size.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dsim {
+// development A/B: DSIM_GN_ONEPASS=0 keeps the two-pass kernels at every level
+int g_gn_onepass = [] { const char* e = getenv("DSIM_GN_ONEPASS"); return e ? atoi(e) : 1; }();
 namespace {
 
 constexpr int GN_THREADS = 256;
@@ -395,6 +399,126 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__
     }
 }
 
+// One-pass GroupNorm for the low-resolution levels (16 x 16 and 8 x 8 maps: 52 of the 83 GroupNorm launches of an SD1.5
+// forward, 35 % of their time): a workgroup takes ALL HW rows of a channel slab made of whole groups of one image and keeps
+// them in registers (<= MAXCH 16-byte chunks per thread), so the tensor is read once instead of twice and one launch
+// replaces two.  grid (P slabs, B); a thread owns one chunk column and every R-th row, exactly like the two-pass kernels,
+// and the statistics use the same per-channel f32 partials -> fixed-order f64 fold per group (bit-reproducible,
+// independent of the batch size).
+template <typename T, bool SILU, int MAXCH>
+__global__ __launch_bounds__(GN_THREADS) void gn_onepass_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1,
+                                                                int C1, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, T* __restrict__ out, int HW,
+                                                                int groups, float eps, int CS) {
+    constexpr int VEC = Vec16<T>::N;
+    typedef typename Vec16<T>::type V;
+    extern __shared__ __attribute__((aligned(16))) char smem_op[];
+    __shared__ float s_mean[64], s_rstd[64];
+    const int C = C0 + C1, cpg = C / groups;
+    const int tpr = CS / VEC;                                  // threads per row (chunk columns of the slab)
+    const int R = GN_THREADS / tpr;                            // rows in flight
+    const int tid = threadIdx.x, trow = tid / tpr, tcol = tid - trow * tpr;
+    const int b = blockIdx.y, c0 = blockIdx.x * CS;            // first channel of this slab
+    const int ch = c0 + tcol * VEC;                            // first channel of this thread's chunks
+    const bool live = trow < R;
+    V v[MAXCH];
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = 0.f;
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int r = trow + i * R;
+            if (r < HW) v[i] = load_slot<T>(x0, C0, x1, C1, (size_t)b * HW + r, ch);
+        }
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            const int r = trow + i * R;
+            if (r < HW) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float f = (float)v[i][e];
+                    s1[e] += f;
+                    s2[e] = fmaf(f, f, s2[e]);
+                }
+            }
+        }
+    }
+    float* lds = reinterpret_cast<float*>(smem_op);            // [R][CS][2]
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            lds[((size_t)trow * CS + tcol * VEC + e) * 2 + 0] = s1[e];
+            lds[((size_t)trow * CS + tcol * VEC + e) * 2 + 1] = s2[e];
+        }
+    }
+    __syncthreads();
+    const int gslab = CS / cpg;                                // whole groups in this slab
+    if (tid < gslab) {
+        double a = 0.0, q = 0.0;
+        for (int rr = 0; rr < R; ++rr)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+                a += (double)lds[((size_t)rr * CS + c) * 2 + 0];
+                q += (double)lds[((size_t)rr * CS + c) * 2 + 1];
+            }
+        const double n = (double)HW * cpg;
+        const double mean = a / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[tid] = (float)mean;
+        s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    if (!live) return;
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int c = ch + e, g = (c - c0) / cpg;
+        const float w = gamma[c] * s_rstd[g];
+        sc[e] = w;
+        sh[e] = beta[c] - s_mean[g] * w;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int r = trow + i * R;
+        if (r < HW) {
+            V o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float y = fmaf((float)v[i][e], sc[e], sh[e]);
+                if (SILU) y = silu_fast(y);
+                o[e] = (T)y;
+            }
+            *reinterpret_cast<V*>(out + ((size_t)b * HW + r) * C + ch) = o;
+        }
+    }
+}
+
+// slab width (channels) of the one-pass form for this shape, or 0 when it does not apply: whole groups, 16-byte chunk
+// columns of at least 256 B per row, no slab straddling the two concat sources, at most MAXCH chunks per thread
+constexpr int GN_OP_MAXCH = 24;
+template <typename T>
+int gn_onepass_slab(int C0, int C1, int B, int HW, int groups) {
+    constexpr int VEC = Vec16<T>::N;
+    const int C = C0 + C1, cpg = C / groups;
+    // The choice depends on the SHAPE only, never on the batch: slab width sets the summation grouping, and a batch of N
+    // must score bit for bit like N single images.  Widest legal slab = longest coalesced row segments.
+    (void)B;
+    int best = 0;
+    for (int gs = 1; gs <= groups; gs *= 2) {                  // groups per slab
+        const int CS = gs * cpg;
+        if (groups % gs || CS % VEC || CS / VEC > GN_THREADS) continue;
+        if (CS * (int)sizeof(T) < 256) continue;               // row segments shorter than 256 B waste the memory pipe
+        if (C1 && (C0 % CS)) continue;                         // a slab may not straddle the concat boundary
+        if (C / CS < 2) continue;                              // at least two workgroups per image
+        const int tpr = CS / VEC, R = GN_THREADS / tpr;
+        if ((HW + R - 1) / R > GN_OP_MAXCH) continue;
+        if ((size_t)R * CS * 2 * sizeof(float) > 48 * 1024) continue;
+        best = CS;
+    }
+    return best;
+}
+
 template <typename T, int NS, int UNR>
 int gn_launch(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta, void* out, int B,
               int HW, int groups, float eps, int silu, void* scratch, int chunks, int rb, size_t lds, hipStream_t s) {
@@ -419,6 +543,18 @@ int gn_typed(const void* x0, int C0, const void* x1, int C1, const float* gamma,
     if (!x1) C1 = 0;
     if (C % groups || C0 % VEC || C1 % VEC || groups > 64 || C > GN_MAX_SLOTS * GN_THREADS * VEC)
         return DSIM_ERR_INVALID;
+    if (const int CS = g_gn_onepass ? gn_onepass_slab<T>(C0, C1, B, HW, groups) : 0) {
+        const int tpr1 = CS / VEC, R1 = GN_THREADS / tpr1;
+        const size_t lds1 = (size_t)R1 * CS * 2 * sizeof(float);
+        if (silu)
+            hipLaunchKernelGGL((gn_onepass_kernel<T, true, GN_OP_MAXCH>), dim3(C / CS, B), dim3(GN_THREADS), lds1, s, (const T*)x0, C0,
+                               (const T*)x1, C1, gamma, beta, (T*)out, HW, groups, eps, CS);
+        else
+            hipLaunchKernelGGL((gn_onepass_kernel<T, false, GN_OP_MAXCH>), dim3(C / CS, B), dim3(GN_THREADS), lds1, s, (const T*)x0, C0,
+                               (const T*)x1, C1, gamma, beta, (T*)out, HW, groups, eps, CS);
+        DSIM_HIP_CHECK(hipGetLastError());
+        return DSIM_OK;
+    }
     const int S = C / VEC, tpr = S < GN_THREADS ? S : GN_THREADS, R = GN_THREADS / tpr;
     const int chunks = gn_chunks(HW);
     const size_t lds = (size_t)R * C * 2 * sizeof(float);
@@ -439,6 +575,13 @@ int gn_typed(const void* x0, int C0, const void* x1, int C1, const float* gamma,
 }
 
 }  // namespace
+
+// passes over the tensor the GroupNorm of this shape makes (2 = one-pass form: read + write; 3 = statistics read + read + write)
+int groupnorm_passes(int C0, int C1, int HW, int groups, int dtype) {
+    if (!g_gn_onepass) return 3;
+    const int cs = dtype == DSIM_F32 ? gn_onepass_slab<float>(C0, C1, 1, HW, groups) : gn_onepass_slab<bf16>(C0, C1, 1, HW, groups);
+    return cs ? 2 : 3;
+}
 
 size_t groupnorm_scratch_bytes(int B, int groups) { return (size_t)B * 64 * groups * 2 * sizeof(double); }
 

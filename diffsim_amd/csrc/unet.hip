@@ -123,7 +123,8 @@ struct Walk {
         if (!run) return DSIM_OK;
         const double n = (double)B2 * x0.H * x0.W * (x0.C + (x1 ? x1->C : 0));
         pbegin(std::string("groupnorm_") + dtn() + "|B" + std::to_string(B2) + " HW" + std::to_string(x0.H * x0.W) + " C" +
-                   std::to_string(x0.C + (x1 ? x1->C : 0)), 0.0, 3.0 * n * es());      // read (stats) + read + write
+                   std::to_string(x0.C + (x1 ? x1->C : 0)), 0.0,
+               (double)groupnorm_passes(x0.C, x1 ? x1->C : 0, x0.H * x0.W, h->cfg.norm_num_groups, h->dt) * n * es());
         const int st = launch_groupnorm(x0.p, x0.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, (const float*)g->p,
                                         (const float*)b->p, out, B2, x0.H * x0.W, h->cfg.norm_num_groups, eps, silu,
                                         h->dt, gn_scratch, s);

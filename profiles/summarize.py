@@ -52,8 +52,7 @@ def short(n):
     return re.sub(r"\(.*$", "", n)
 
 
-def main():
-    tag, trace, fetch, write = sys.argv[1:5]
+def write_stats(tag, trace):
     stats = glob.glob(os.path.join(trace, "**", "*kernel_stats.csv"), recursive=True)[0]
     rows = list(csv.DictReader(open(stats)))
     dm = demangle([r["Name"] for r in rows])
@@ -63,6 +62,15 @@ def main():
         for r in rows:
             w.writerow([short(dm[r["Name"]]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                         r["MinNs"], r["MaxNs"]])
+
+
+def main():
+    if sys.argv[1] == "--stats-only":          # python profiles/summarize.py --stats-only <tag> <trace dir>
+        write_stats(sys.argv[2], sys.argv[3])
+        print("wrote", sys.argv[2])
+        return
+    tag, trace, fetch, write = sys.argv[1:5]
+    write_stats(tag, trace)
     pmc = collections.defaultdict(lambda: {"launches": 0, "FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0})
     for d, key in ((fetch, "FETCH_SIZE_KB"), (write, "WRITE_SIZE_KB")):
         f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]

@@ -100,7 +100,12 @@ def test_conv3x3(eng, dtype, B, H, W, Cin, Cout, stride, ups):
 @pytest.mark.parametrize("B,HW,C0,C1,silu,eps", [
     (2, 256, 320, 0, True, 1e-5), (3, 64, 1280, 640, True, 1e-5), (2, 4096, 320, 0, False, 1e-6),
     (2, 16, 256, 128, True, 1e-5), (1, 1, 1280, 1280, True, 1e-5), (2, 1024, 64, 0, True, 1e-5),
-    (2, 40000, 128, 0, True, 1e-6)])        # a VAE-sized map: 64 statistics slabs per image, ragged slab lengths
+    (2, 40000, 128, 0, True, 1e-6),         # a VAE-sized map: 64 statistics slabs per image, ragged slab lengths
+    # the one-pass form (register-resident slabs of whole groups) at the 16 x 16 / 8 x 8 level shapes: single source,
+    # both concat widths (2560 = one-pass, 1920 = 60-channel groups straddle 16-byte chunks -> two-pass), wide batch
+    (3, 256, 1280, 0, True, 1e-5), (2, 256, 1280, 1280, True, 1e-5), (2, 256, 1280, 640, True, 1e-5),
+    (2, 64, 1280, 1280, True, 1e-5), (5, 64, 1280, 0, False, 1e-6), (2, 256, 640, 0, True, 1e-5),
+    (130, 64, 1280, 0, True, 1e-5), (2, 100, 320, 0, True, 1e-5), (2, 576, 1280, 0, True, 1e-5)])
 def test_groupnorm(eng, dtype, B, HW, C0, C1, silu, eps):
     g = torch.Generator().manual_seed(HW + C0 + C1)
     C = C0 + C1

@@ -347,7 +347,12 @@ def headline(a, world, rank, dev):
     ia = torch.arange(0, 2 * bp, 2, dtype=torch.int32, device=dev)
     ib = ia + 1
     shape = (2 * bp, 2, eng.tokens, eng.heads * eng.head_dim)
-    qkv = tuple(torch.empty(shape, dtype=dtype, device=dev) for _ in range(3))
+    # A step scores NS independent sub-batches of bp pairs, each enqueued on its own HIP stream: the HBM-bound kernels of
+    # one sub-batch (norms) run under the MFMA-bound kernels of the other (profiles/r02_two_stream.txt)
+    NS = 1 if a.pixels_in else max(1, a.streams)
+    qkvs = [tuple(torch.empty(shape, dtype=dtype, device=dev) for _ in range(3)) for _ in range(NS)]
+    qkv = qkvs[0]
+    side = [torch.cuda.Stream(device=dev) for _ in range(NS)] if NS > 1 else []
 
     if a.pixels_in:
         from diffsim_amd.engine import VAEEncoder
@@ -361,12 +366,23 @@ def headline(a, world, rank, dev):
             mean, logvar = mom.chunk(2, dim=1)
             z = (mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * eps) * 0.18215
             q, k, v = eng.qkv(z.contiguous(), nz, sa, sb, ctx, out=qkv)
-        else:
+        elif NS == 1:
             q, k, v = eng.qkv(lat_all[i % NB], nz, sa, sb, ctx, out=qkv)
+        else:
+            main = torch.cuda.current_stream()
+            parts = []
+            for h, st in enumerate(side):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    q, k, v = eng.qkv(lat_all[(i * NS + h) % NB], nz, sa, sb, ctx, out=qkvs[h])
+                    parts.append(pair_score(q, k, v, ia, ib, eng.heads, "cosine"))
+            for st in side:
+                main.wait_stream(st)
+            return torch.cat(parts)
         return pair_score(q, k, v, ia, ib, eng.heads, "cosine")
 
     el, scores, seen = timed_steps(step, a, world, dev)
-    pairs_per_s = world * a.steps * bp / el
+    pairs_per_s = world * a.steps * bp * NS / el
     out = {
         "metric": "image-pairs/sec at 512px, SD1.5 up_blocks[0] t=600",
         "value": round(pairs_per_s, 3), "unit": "pairs/s", "n_gpus": world, "n_ranks_seen": seen, "steps": a.steps,
@@ -375,7 +391,8 @@ def headline(a, world, rank, dev):
         "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": "DiffSim SD1.5, synthetic 512px pairs (%s), up_blocks[0] t=600 (t=401), cosine"
                                % ("pixels-in incl. VAE encoder" if a.pixels_in else "latents-in"),
-                   "pairs_per_step_per_gpu": bp, "distinct_pairs_resident_per_gpu": bp * (1 if a.pixels_in else NB),
+                   "pairs_per_step_per_gpu": bp * NS, "concurrent_sub_batches": NS, "pairs_per_sub_batch": bp,
+                   "distinct_pairs_resident_per_gpu": bp * (1 if a.pixels_in else NB),
                    "gflop_per_pair": GFLOP_PER_PAIR, "parallelism": f"pairs sharded x{world}"},
         "whole_path_tflops_per_gpu": round(pairs_per_s / world * GFLOP_PER_PAIR / 1e3, 2),
         "score_sample": [round(float(x), 6) for x in scores[:4].float().cpu()],
@@ -406,7 +423,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch-pairs", type=int, default=32, help="pairs per step per GPU")
+    ap.add_argument("--batch-pairs", type=int, default=32, help="pairs per sub-batch (one U-Net batch = 4 x this many elements)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="concurrent sub-batches per step, one HIP stream each (headline line; a step scores streams x batch-pairs pairs)")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--resident-batches", type=int, default=4,
                     help="distinct synthetic batches kept in HBM; the timed steps cycle through them")

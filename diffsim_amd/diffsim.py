@@ -85,6 +85,7 @@ class DiffSim:
         self._engines: Dict[Tuple[str, int], object] = {}
         self._ctx: Dict[str, torch.Tensor] = {}
         self._pool = ThreadPoolExecutor(max_workers=16)     # host-side image decode / resize
+        self._streams: List[torch.cuda.Stream] = []          # side streams of score_latent_pairs
 
     # ------------------------------------------------------------------------------------------
     def engine(self, target_block: str, target_layer: int) -> UNetEngine:
@@ -159,23 +160,44 @@ class DiffSim:
 
     @torch.no_grad()
     def score_latent_pairs(self, latA, latB, noiseA, noiseB, prompt, target_block="up_blocks", target_layer=0,
-                           target_step=600, similarity="cosine", batch_pairs: int = 16) -> torch.Tensor:
+                           target_step=600, similarity="cosine", batch_pairs: int = 16, streams: int = 2) -> torch.Tensor:
         """Batched latents-in scoring: pair i = (latA[i], latB[i]) -> scores (n,) f32 on device.
-        noiseA/noiseB are (1,4,s,s) (shared by every pair: each reference call reseeds) or (n,4,s,s)."""
+        noiseA/noiseB are (1,4,s,s) (shared by every pair: each reference call reseeds) or (n,4,s,s).
+        Consecutive chunks of `batch_pairs` pairs are enqueued on `streams` HIP streams in turn, so the HBM-bound kernels of
+        one chunk overlap the MFMA-bound kernels of the next (same kernels, same scores)."""
         n = latA.shape[0]
         eng = self.engine(target_block, target_layer)
         out = torch.empty(n, dtype=torch.float32, device=self.device)
         batch_pairs = max(1, min(batch_pairs, eng.max_images() // 2))      # every activation must stay < 2 GiB
-        for i0 in range(0, n, batch_pairs):
+        starts = list(range(0, n, batch_pairs))
+        ns = max(1, min(int(streams), len(starts)))
+        if self.use_graphs:
+            ns = 1
+        main = torch.cuda.current_stream(self.device)
+        if ns > 1:
+            if len(self._streams) < ns:
+                self._streams += [torch.cuda.Stream(device=self.device) for _ in range(ns - len(self._streams))]
+            # everything the chunks share is produced on the main stream BEFORE the side streams fork from it: the prompt
+            # context and the timestep tables (set_timestep enqueues kernels; a later chunk on another stream would see
+            # "already set" on the host while those kernels are still running)
+            ctx_ready = self.context(prompt)
+            eng.set_timestep(sched.timestep_from_index(int(target_step)))
+            for st in self._streams[:ns]:
+                st.wait_stream(main)
+        for ci, i0 in enumerate(starts):
             i1 = min(n, i0 + batch_pairs)
             m = i1 - i0
-            lat = torch.stack([latA[i0:i1], latB[i0:i1]], dim=1).reshape(2 * m, *latA.shape[1:])
-            nA = noiseA[i0:i1] if noiseA.shape[0] == n else noiseA.expand(m, *noiseA.shape[1:])
-            nB = noiseB[i0:i1] if noiseB.shape[0] == n else noiseB.expand(m, *noiseB.shape[1:])
-            nz = torch.stack([nA, nB], dim=1).reshape(2 * m, *latA.shape[1:])
-            q, k, v = self.features(lat, nz, prompt, target_block, target_layer, target_step)
-            ia = torch.arange(0, 2 * m, 2, dtype=torch.int32, device=self.device)
-            out[i0:i1] = pair_score(q, k, v, ia, ia + 1, eng.heads, similarity)
+            with torch.cuda.stream(self._streams[ci % ns] if ns > 1 else main):
+                lat = torch.stack([latA[i0:i1], latB[i0:i1]], dim=1).reshape(2 * m, *latA.shape[1:])
+                nA = noiseA[i0:i1] if noiseA.shape[0] == n else noiseA.expand(m, *noiseA.shape[1:])
+                nB = noiseB[i0:i1] if noiseB.shape[0] == n else noiseB.expand(m, *noiseB.shape[1:])
+                nz = torch.stack([nA, nB], dim=1).reshape(2 * m, *latA.shape[1:])
+                q, k, v = self.features(lat, nz, prompt if ns == 1 else ctx_ready, target_block, target_layer, target_step)
+                ia = torch.arange(0, 2 * m, 2, dtype=torch.int32, device=self.device)
+                out[i0:i1] = pair_score(q, k, v, ia, ia + 1, eng.heads, similarity)
+        if ns > 1:
+            for st in self._streams[:ns]:
+                main.wait_stream(st)
         return out
 
     @torch.no_grad()

@@ -113,7 +113,7 @@ class UNetEngine:
             del keep
         self.sample_size = cfg.sample_size
         self._refresh_tap_shape()
-        self._ws: Optional[torch.Tensor] = None
+        self._ws_by_stream: Dict[int, torch.Tensor] = {}      # one arena per HIP stream the engine is driven from
         self._graphs: Dict[tuple, tuple] = {}
         self.use_graphs = False
         self._profiling = False
@@ -238,10 +238,15 @@ class UNetEngine:
             if need == 0:
                 raise _lib.DsimError(f"{n} images do not fit one call (an activation would reach 2 GiB): at most "
                                      f"{self.max_images()} images per call for this graph")
-            if self._ws is None or self._ws.numel() < need:
-                self._ws = None
+            # dsim_unet_qkv keeps no per-call state in the handle, so independent batches may be in flight on several
+            # streams at once (one host thread): each stream gets its own workspace arena
+            sid = _stream_ptr()
+            ws = self._ws_by_stream.get(sid)
+            if ws is None or ws.numel() < need:
+                self._ws_by_stream.pop(sid, None)
                 self._graphs.clear()                 # captured graphs hold the old arena's addresses
-                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                ws = self._ws_by_stream[sid] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws = ws
             shape = (n, 2, self.tokens, self.heads * self.head_dim)
             if self.use_graphs and out is None and not self._profiling:
                 return self._replay(latents, noise, float(sqrt_abar), float(sqrt_1m_abar), ctx, shape)

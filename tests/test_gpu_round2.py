@@ -196,3 +196,21 @@ def test_cli_end_to_end(tmp_path, golden_dir, capsys, monkeypatch):
         ac = ds.diffsim(a, c, 128, prompt, "up_blocks", [0], 600, seed=2334, similarity="cosine")
         c1 += int(ab > ac)
     assert f"Total {len(trip)}; Correct {c1};" in out
+
+
+def test_chunks_on_two_streams_score_like_one_stream():
+    """score_latent_pairs enqueues consecutive chunks on two HIP streams (overlap of HBM-bound and MFMA-bound kernels):
+    bit-identical to the single-stream run, also when the first chunk has to set the timestep tables first."""
+    sd = S.make_state_dict(C.TINY, seed=0)
+    ctx = S.make_context(C.TINY)
+    lat = [S.make_pair_latents(C.TINY, i) for i in range(7)]
+    zA, zB = torch.cat([p[0] for p in lat]), torch.cat([p[1] for p in lat])
+    n = S.draw_pair_noise(2334, lat[0][0].shape)
+    for dtype in (torch.bfloat16, torch.float32):
+        one = _ds(C.TINY, sd, dtype).score_latent_pairs(zA, zB, n[2], n[3], ctx, "up_blocks", 0, 600, "cosine", batch_pairs=2, streams=1)
+        for _ in range(3):
+            two = _ds(C.TINY, sd, dtype).score_latent_pairs(zA, zB, n[2], n[3], ctx, "up_blocks", 0, 600, "cosine", batch_pairs=2, streams=2)
+            assert torch.equal(one, two)
+        three = _ds(C.TINY, sd, dtype).score_latent_pairs(zA, zB, n[2], n[3], ctx, "down_blocks", 1, 750, "mse", batch_pairs=3, streams=3)
+        ref = _ds(C.TINY, sd, dtype).score_latent_pairs(zA, zB, n[2], n[3], ctx, "down_blocks", 1, 750, "mse", batch_pairs=3, streams=1)
+        assert torch.equal(three, ref)

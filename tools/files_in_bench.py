@@ -55,6 +55,7 @@ n_enc[0] = 0
 torch.cuda.synchronize(); t0 = time.perf_counter()
 sl, sr, bad = H.score_path_triplets(ds, trip, 512, "up_blocks", [0], 600, 2334, "cosine", batch_triplets=10)
 torch.cuda.synchronize(); dt_trip = time.perf_counter() - t0
+prompt_encodes = n_enc[0] // 2                     # two tokenisations (negative, positive) per encoded prompt
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(20):
     enc(tokenize(f"prompt {i}"))
@@ -62,6 +63,6 @@ torch.cuda.synchronize(); dt_txt = (time.perf_counter() - t0) / 20
 print(json.dumps({"probe": "files-in (decode + resize + VAE + text + U-Net + tail), SD1.5 512 px, bf16, synthetic weights",
                   "pairs_per_s_one_prompt": round(len(pairs) / dt_pairs, 1), "pairs": len(pairs),
                   "triplets_per_s_per_row_prompts": round(len(trip) / dt_trip, 1), "pair_scores_per_s_triplets": round(2 * len(trip) / dt_trip, 1),
-                  "triplets": len(trip), "distinct_prompts": 12, "prompt_encodes": n_enc[0] // 2, "nonfinite_scores": bad,
+                  "triplets": len(trip), "distinct_prompts": 12, "prompt_encodes": prompt_encodes, "nonfinite_scores": bad,
                   "clip_l_text_encoder_ms_per_prompt": round(1e3 * dt_txt, 2), "host_cpu_count": os.cpu_count(),
                   "score_sample": [round(float(x), 5) for x in s[:3]]}))

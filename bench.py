@@ -424,8 +424,11 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch-pairs", type=int, default=32, help="pairs per sub-batch (one U-Net batch = 4 x this many elements)")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="concurrent sub-batches per step, one HIP stream each (headline line; a step scores streams x batch-pairs pairs)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="concurrent sub-batches per step, one HIP stream each (a step then scores streams x batch-pairs pairs).  "
+                         "2 is ~2 %% faster (one sub-batch's norm kernels run under the other's GEMMs) and is what "
+                         "DiffSim.score_latent_pairs does; the default stays 1 so that every kernel of the timed region runs alone on "
+                         "the chip and its rocprofv3 duration is the kernel's own (the roofline leg divides by it)")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--resident-batches", type=int, default=4,
                     help="distinct synthetic batches kept in HBM; the timed steps cycle through them")

@@ -543,7 +543,7 @@ class UNet2DConditionModel(nn.Module):
     def forward(self, sample, t, ctx, stats: Optional[dict] = None, added_cond_kwargs: Optional[dict] = None):
         """Full forward to ``conv_out`` (what diffsim_pipeline.py:213-221 executes)."""
         b = sample.shape[0]
-        wd = self.conv_in.weight.dtype        # float32; float64 when the oracle is evaluated in double (tools/sdxl_f64_probe.py)
+        wd = self.conv_in.weight.dtype        # float32; float64 when the oracle is evaluated in double (tests/probe_sdxl_f64.py)
         tt = torch.full((b,), float(t), dtype=torch.float32)
         temb = self.time_embedding(timestep_embedding(tt, self.cfg.block_out_channels[0]).to(wd))
         if self.cfg.addition_embed:

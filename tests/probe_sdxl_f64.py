@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU box): how far are (a) the fp32 HIP path and (b) the fp32 torch-CPU oracle from the SAME SDXL graph
 evaluated in float64?  Separates kernel error from the fp32 conditioning of a 34-transformer-block random-weight network
-(tests/test_gpu_fullsize.py::test_sdxl_1024px_two_taps quotes the result).  Usage: python tools/sdxl_f64_probe.py"""
+(tests/test_gpu_fullsize.py::test_sdxl_1024px_two_taps quotes the result).  Test infrastructure (it runs the oracle), not
+collected by pytest.  Usage: python tests/probe_sdxl_f64.py"""
 import os
 import sys
 import time

@@ -57,7 +57,7 @@ def test_sdxl_1024px_two_taps():
 
     The oracle is evaluated in FLOAT64 here.  34 transformer blocks of random weights sit in front of these taps and
     torch's fp32 CPU kernels are themselves 1.0e-4 (relative, on the score) away from the float64 evaluation of the same
-    graph, while the HIP fp32 mode is 2e-8 / 5e-8 away (tools/sdxl_f64_probe.py, profiles/r02_sdxl_f64_probe.txt): against
+    graph, while the HIP fp32 mode is 2e-8 / 5e-8 away (tests/probe_sdxl_f64.py, profiles/r02_sdxl_f64_probe.txt): against
     the fp32 CPU numbers the 1e-4 gate would measure the CPU library's rounding, not the kernels'."""
     from oracle import cpu_ref as R
     from diffsim_amd.diffsim_xl import diffsim_xl

@@ -27,6 +27,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG
 for t in trace_sdxl trace_pixels; do find $R/gpurun_out/prof_${TAG}_$t -type f ! -name "*kernel_stats.csv" -delete; done
 cd $R
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.log; echo bench rc=$?
+python3 bench.py --steps 20 --warmup 5 --streams 2 --no-cpu-baseline > gpurun_out/bench_${TAG}_two_streams.json 2> gpurun_out/bench_${TAG}_two_streams.log; echo two_streams rc=$?
 python3 bench.py --model sdxl --batch-pairs 8 --steps 6 --warmup 2 > gpurun_out/bench_${TAG}_sdxl.json 2> gpurun_out/bench_${TAG}_sdxl.log; echo sdxl rc=$?
 python3 bench.py --model dit --batch-pairs 64 --steps 10 --warmup 3 > gpurun_out/bench_${TAG}_dit.json 2> gpurun_out/bench_${TAG}_dit.log; echo dit rc=$?
 python3 bench.py --model dit --fp8-attention --batch-pairs 64 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_${TAG}_dit_fp8.json 2> gpurun_out/bench_${TAG}_dit_fp8.log; echo ditfp8 rc=$?

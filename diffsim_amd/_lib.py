@@ -70,6 +70,7 @@ SYMBOLS = {
     "dsim_unet_tap_shape": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "dsim_unet_set_tap": (_i, [_vp, _i, _i, _i, _i]),
     "dsim_unet_set_sample_size": (_i, [_vp, _i]),
+    "dsim_unet_set_cfg_dedup": (_i, [_vp, _i]),
     "dsim_unet_profile": (_i, [_vp, _i]),
     "dsim_unet_profile_count": (_i, [_vp]),
     "dsim_unet_profile_get": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double),

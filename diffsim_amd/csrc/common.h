@@ -85,6 +85,8 @@ int prep_conv_in(const float* lat, const float* noise /*nullable*/, float sa, fl
                  const float* bias, void* out, int dtype, int n_img, int Cin, int S, int Cout, int dup /*1|2*/,
                  hipStream_t st);
 int convert_f32_to(const float* src, void* dst, int dtype, size_t n, hipStream_t s);
+// out[2b], out[2b+1] = in[b]: a batch element becomes its two classifier-free-guidance copies (bytes_per_elem % 16 == 0)
+int dup_batch(const void* in, void* out, int n_batch, size_t bytes_per_elem, hipStream_t s);
 
 // norms -- norm.hip
 size_t groupnorm_scratch_bytes(int B, int groups);

@@ -240,6 +240,24 @@ int prep_conv_in(const float* lat, const float* noise, float sa, float sb, const
     DSIM_HIP_CHECK(hipGetLastError());
     return DSIM_OK;
 }
+// out[(b * 2 + c)][i] = in[b][i] for c in {0, 1}: one batch element of `per` 16-byte chunks becomes its two CFG copies
+__global__ void dup_batch_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, size_t per, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t b = i / per, r = i - b * per;
+    const u32x4 v = in[i];
+    out[(2 * b) * per + r] = v;
+    out[(2 * b + 1) * per + r] = v;
+}
+
+int dup_batch(const void* in, void* out, int n_batch, size_t bytes_per_elem, hipStream_t s) {
+    if (bytes_per_elem % 16) return DSIM_ERR_INVALID;
+    const size_t per = bytes_per_elem / 16, total = per * (size_t)n_batch;
+    hipLaunchKernelGGL(dup_batch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const u32x4*)in, (u32x4*)out, per, total);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+
 int convert_f32_to(const float* src, void* dst, int dtype, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, dtype, n);
     DSIM_HIP_CHECK(hipGetLastError());

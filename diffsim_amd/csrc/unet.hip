@@ -30,6 +30,7 @@ struct dsim_unet : WeightStore {
     float* temb = nullptr;          // [time_embed_dim]
     float* tscratch = nullptr;      // time-embedding scratch
     bool two_temb = false;          // SDXL: the CFG halves carry different time embeddings
+    bool cfg_dedup = false;         // opt-in: compute the part of the graph that is identical in both CFG halves once
 };
 
 namespace {
@@ -184,8 +185,12 @@ struct Walk {
     // Transformer2DModel (GroupNorm -> proj_in -> `depth` BasicTransformerBlocks -> proj_out -> +residual; the
     // conv1x1 and the Linear form of proj_in/out are the same GEMM on token-major data).  tap_blk >= 0 stops
     // after norm1 of that transformer block and emits q,k,v (-2 = never, -1 = the last block).
-    int transformer(const std::string& p, const Act& x, int level, int tap_blk, Act* out) {
+    // half_in: x holds ONE copy per image (B2 / 2 batch elements, opt-in CFG de-duplication): everything up to the first
+    // cross-attention -- the first place the prompt context enters -- runs on that half batch, then the residual stream, the
+    // block input and the cross-attention query are duplicated into [image][cfg] order and the rest runs as usual.
+    int transformer(const std::string& p, const Act& x, int level, int tap_blk, Act* out, bool half_in = false) {
         const int C = x.C, HW = x.H * x.W, M = B2 * HW, H = heads_at(level), D = C / H;
+        const int Bfull = B2, Mh = (B2 / 2) * HW;
         const int L = h->cfg.ctx_len, Dc = h->cfg.cross_attention_dim;
         const int depth = depth_at(level);
         if (tap_blk == -1) tap_blk = depth - 1;
@@ -196,9 +201,19 @@ struct Walk {
         if (!tap_here) { out->p = alloc_act((size_t)M * C); out->C = C; out->H = x.H; out->W = x.W; }
         const size_t mk = ar->mark();
         void* t1 = alloc_act((size_t)M * C);
-        CK(gn(x, nullptr, gnw, gnb, t1, 1e-6f, 0));
         void* hb = alloc_act((size_t)M * C);
-        CK(linear(t1, C, nullptr, 0, piw, pib, nullptr, hb, M, C, C));
+        void* hbh = half_in ? alloc_act((size_t)Mh * C) : nullptr;      // half-batch residual stream / query / full-batch input copy
+        void* abh = half_in ? alloc_act((size_t)Mh * C) : nullptr;
+        void* xfull = half_in ? alloc_act((size_t)M * C) : nullptr;
+        const void* xres = half_in ? xfull : x.p;                       // residual of proj_out: the block input, full batch
+        if (half_in) {
+            if (tap_blk == 0) return DSIM_ERR_INVALID;                  // (callers never de-duplicate a tapped first block)
+            B2 = Bfull / 2;
+        }
+        const int M0 = half_in ? Mh : M;                                // rows of the part before the first cross-attention
+        void* hb0 = half_in ? hbh : hb;
+        CK(gn(x, nullptr, gnw, gnb, t1, 1e-6f, 0));
+        CK(linear(t1, C, nullptr, 0, piw, pib, nullptr, hb0, M0, C, C));
         void* nb = t1;                                   // t1 is dead: reuse it for LayerNorm outputs
         void* big = nullptr;
         void* ab = nullptr;
@@ -207,7 +222,10 @@ struct Walk {
         const std::string b = p + "transformer_blocks." + std::to_string(blk) + ".";
         WGET(l1w, b + "norm1.weight"); WGET(l1b, b + "norm1.bias");
         WGET(qkv, b + "attn1.qkv");
-        CK(ln(hb, l1w, l1b, nb, M, C));
+        const bool pre = half_in && blk == 0;            // still on the de-duplicated half batch
+        const int Mx = pre ? Mh : M;
+        void* hbx = pre ? hbh : hb;
+        CK(ln(hbx, l1w, l1b, nb, Mx, C));
         if (blk == tap_blk) {
             // hacked_attn.py:61-69: to_q / to_k / to_v, no bias; written [B][N][H*D]
             Packed wq = *qkv, wk = *qkv, wv = *qkv;
@@ -233,18 +251,31 @@ struct Walk {
             ab = alloc_act((size_t)M * C);
             kvb = alloc_act((size_t)2 * L * 2 * C);
         }
-        CK(linear(nb, C, nullptr, 0, qkv, nullptr, nullptr, big, M, 3 * C, 3 * C));
+        CK(linear(nb, C, nullptr, 0, qkv, nullptr, nullptr, big, Mx, 3 * C, 3 * C));
         {
             AttnArgs a;
             a.q = big; a.ldq = 3 * C;
             a.k = (char*)big + (size_t)C * es(); a.v = (char*)big + (size_t)2 * C * es(); a.ldk = 3 * C;
-            a.out = ab; a.ldo = C; a.B = B2; a.Bkv = B2; a.H = H; a.Nq = HW; a.Nk = HW; a.D = D;
+            a.out = pre ? abh : ab; a.ldo = C; a.B = B2; a.Bkv = B2; a.H = H; a.Nq = HW; a.Nk = HW; a.D = D;
             CK(attn(a));
         }
-        CK(linear(ab, C, nullptr, 0, o1w, o1b, hb, hb, M, C, C));
+        CK(linear(pre ? abh : ab, C, nullptr, 0, o1w, o1b, hbx, hbx, Mx, C, C));
         // cross-attention against the prompt context: batch element b uses ctx[b % 2]
-        CK(ln(hb, l2w, l2b, nb, M, C));
-        CK(linear(nb, C, nullptr, 0, q2w, nullptr, nullptr, ab, M, C, C));
+        CK(ln(hbx, l2w, l2b, nb, Mx, C));
+        CK(linear(nb, C, nullptr, 0, q2w, nullptr, nullptr, pre ? abh : ab, Mx, C, C));
+        if (pre) {
+            // the two CFG halves part here: [image] -> [image][cfg] for the residual stream, the query and the block input
+            B2 = Bfull;
+            if (run) {
+                const size_t per = (size_t)HW * C * es();
+                pbegin(std::string("cfg_duplicate_") + dtn(), 0.0, 3.0 * 3.0 * Mh * (double)C * es());
+                int st = dup_batch(hbh, hb, Bfull / 2, per, s);
+                if (st == DSIM_OK) st = dup_batch(abh, ab, Bfull / 2, per, s);
+                if (st == DSIM_OK) st = dup_batch(x.p, xfull, Bfull / 2, per, s);
+                pend();
+                CK(st);
+            }
+        }
         CK(linear(ctx_t, Dc, nullptr, 0, kv2, nullptr, nullptr, kvb, 2 * L, 2 * C, 2 * C));
         {
             AttnArgs a;
@@ -260,7 +291,7 @@ struct Walk {
         CK(linear(big, 4 * C, nullptr, 0, f2w, f2b, hb, hb, M, C, C));
         }   // transformer blocks
         WGET(pow_, p + "proj_out.weight"); WGET(pob, p + "proj_out.bias");
-        CK(linear(hb, C, nullptr, 0, pow_, pob, x.p, out->p, M, C, C));
+        CK(linear(hb, C, nullptr, 0, pow_, pob, xres, out->p, M, C, C));
         ar->release(mk);
         return DSIM_OK;
     }
@@ -283,19 +314,42 @@ struct Walk {
         }
         std::vector<Act> skips;
         skips.push_back(x);
+        // Opt-in CFG de-duplication (dsim_unet_set_cfg_dedup): the reference feeds torch.cat([latents] * 2) with [negative,
+        // positive] prompt embeddings (diffsim_pipeline.py:208-221), so conv_in, the first ResnetBlock2D and the first
+        // transformer up to its cross-attention query see two bit-identical batch halves.  With one time embedding for both
+        // halves (SD1.5; SDXL's text_time embedding differs per half) and the tap outside that block, they are computed once
+        // per image and duplicated where the prompt context first enters.  Same kernels, batch-invariant: same bits.
+        const bool dedup = h->cfg_dedup && !h->two_temb && c.down_has_attn[0] && c.layers_per_block >= 1 &&
+                           !(c.tap_block == DSIM_TAP_DOWN && c.tap_layer == 0);
+        Act xh{nullptr, ch0, S, S};
+        if (dedup) {
+            xh.p = alloc_act((size_t)(B2 / 2) * S * S * ch0);
+            if (run)
+                CK(prep_conv_in(lat, noise, sa, sb, (const float*)ciw->p, (const float*)cib->p, xh.p, h->dt, B2 / 2, c.in_channels,
+                                S, ch0, 1, s));
+        }
         // ---- down path (hacked_modules.py:583-618) ---------------------------------------
         for (int i = 0; i < nl; ++i) {
             const int co = c.block_out_channels[i];
             const std::string bp = "down_blocks." + std::to_string(i) + ".";
             for (int j = 0; j < c.layers_per_block; ++j) {
+                const bool half = dedup && i == 0 && j == 0;
                 Act r;
-                CK(resnet(bp + "resnets." + std::to_string(j) + ".", x, nullptr, co, &r));
+                if (half) {
+                    const int Bfull = B2;
+                    B2 = Bfull / 2;
+                    const int st = resnet(bp + "resnets.0.", xh, nullptr, co, &r);
+                    B2 = Bfull;
+                    CK(st);
+                } else {
+                    CK(resnet(bp + "resnets." + std::to_string(j) + ".", x, nullptr, co, &r));
+                }
                 x = r;
                 if (c.down_has_attn[i]) {
                     const int ta = c.tap_attn < 0 ? c.layers_per_block - 1 : c.tap_attn;
                     const bool tap = c.tap_block == DSIM_TAP_DOWN && c.tap_layer == i && j == ta;
                     Act t;
-                    CK(transformer(bp + "attentions." + std::to_string(j) + ".", x, i, tap ? c.tap_tfm : -2, &t));
+                    CK(transformer(bp + "attentions." + std::to_string(j) + ".", x, i, tap ? c.tap_tfm : -2, &t, half));
                     if (tap) return DSIM_OK;
                     x = t;
                 }
@@ -579,6 +633,12 @@ int dsim_unet_set_tap(dsim_unet* h, int tap_block, int tap_layer, int tap_attn, 
     }
     if (st != DSIM_OK) h->cfg = old;
     return st;
+}
+
+int dsim_unet_set_cfg_dedup(dsim_unet* h, int enable) {
+    if (!h) return DSIM_ERR_INVALID;
+    h->cfg_dedup = enable != 0;
+    return DSIM_OK;
 }
 
 int dsim_unet_set_sample_size(dsim_unet* h, int side) {

@@ -144,6 +144,12 @@ class UNetEngine:
             self._refresh_tap_shape()
             self._graphs.clear()
 
+    def set_cfg_dedup(self, enable: bool):
+        """Opt-in: compute the part of the graph both CFG halves share once (SD1.5 graphs; bit-identical scores)."""
+        _lib.check(self.L.dsim_unet_set_cfg_dedup(self._h, int(bool(enable))), "dsim_unet_set_cfg_dedup")
+        self._max_images = None
+        self._graphs.clear()
+
     def view(self, target_block: str, target_layer) -> "TapView":
         return TapView(self, target_block, target_layer)
 

@@ -214,3 +214,44 @@ def test_chunks_on_two_streams_score_like_one_stream():
         three = _ds(C.TINY, sd, dtype).score_latent_pairs(zA, zB, n[2], n[3], ctx, "down_blocks", 1, 750, "mse", batch_pairs=3, streams=3)
         ref = _ds(C.TINY, sd, dtype).score_latent_pairs(zA, zB, n[2], n[3], ctx, "down_blocks", 1, 750, "mse", batch_pairs=3, streams=1)
         assert torch.equal(three, ref)
+
+
+def test_cfg_dedup_is_bit_identical():
+    """dedup_cfg=True computes conv_in, the first resnet and the first transformer up to its cross-attention query once per
+    image instead of once per CFG half (the reference's torch.cat([latents] * 2) makes the halves identical there):
+    same kernels on half the batch, so the scores must not change by a bit -- every tap, both dtypes, batches of 1 and 5;
+    a tap inside the first down block and SDXL graphs (per-half time embedding) silently keep the duplicated path."""
+    from diffsim_amd.diffsim_xl import diffsim_xl
+    sd = S.make_state_dict(C.TINY, seed=0)
+    ctx = S.make_context(C.TINY)
+    lat = [S.make_pair_latents(C.TINY, i) for i in range(5)]
+    zA, zB = torch.cat([p[0] for p in lat]), torch.cat([p[1] for p in lat])
+    n = S.draw_pair_noise(2334, lat[0][0].shape)
+    for dtype in (torch.float32, torch.bfloat16):
+        plain, dedup = _ds(C.TINY, sd, dtype), _ds(C.TINY, sd, dtype, dedup_cfg=True)
+        for blk, layer, step in (("up_blocks", 0, 600), ("down_blocks", 1, 750), ("mid_blocks", 0, 900), ("down_blocks", 0, 600),
+                                 ("up_blocks", 2, 500)):
+            a = plain.score_latent_pairs(zA, zB, n[2], n[3], ctx, blk, layer, step, "cosine", batch_pairs=5)
+            b = dedup.score_latent_pairs(zA, zB, n[2], n[3], ctx, blk, layer, step, "cosine", batch_pairs=5)
+            assert torch.equal(a, b), (dtype, blk, layer)
+            assert torch.equal(a[:1], dedup.score_latent_pairs(zA[:1], zB[:1], n[2], n[3], ctx, blk, layer, step, "cosine"))
+        # fewer bytes of workspace are not promised, fewer FLOPs are: the profiled launch list is shorter in work, not in kind
+        eng = dedup.engine("up_blocks", 0)
+        eng.profile(True)
+        dedup.score_latent_pairs(zA[:2], zB[:2], n[2], n[3], ctx, "up_blocks", 0, 600, "cosine")
+        fl_d = sum(r[1] for r in eng.profile_records())
+        eng.profile(False)
+        eng = plain.engine("up_blocks", 0)
+        eng.profile(True)
+        plain.score_latent_pairs(zA[:2], zB[:2], n[2], n[3], ctx, "up_blocks", 0, 600, "cosine")
+        fl_p = sum(r[1] for r in eng.profile_records())
+        eng.profile(False)
+        assert 0.85 * fl_p < fl_d < 0.99 * fl_p
+    xsd = S.make_state_dict(C.SDXL_TINY, seed=0)
+    xctx, pooled = S.make_context(C.SDXL_TINY), S.make_pooled(C.SDXL_TINY)
+    xl = diffsim_xl(torch.float32, "cuda", unet_config=C.SDXL_TINY, state_dict=xsd)
+    g = torch.Generator("cpu").manual_seed(3)
+    za, zb = torch.randn((1, 4, 16, 16), generator=g), torch.randn((1, 4, 16, 16), generator=g)
+    a = xl.score_latent_pairs(za, zb, n[2], n[3], xctx, pooled, "up_blocks", [0, 1, 2], 600)
+    xl.engine("up_blocks", [0, 1, 2]).set_cfg_dedup(True)
+    assert torch.equal(a, xl.score_latent_pairs(za, zb, n[2], n[3], xctx, pooled, "up_blocks", [0, 1, 2], 600))

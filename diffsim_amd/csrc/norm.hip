@@ -19,6 +19,7 @@
 namespace dsim {
 // development A/B: DSIM_GN_ONEPASS=0 keeps the two-pass kernels at every level
 int g_gn_onepass = [] { const char* e = getenv("DSIM_GN_ONEPASS"); return e ? atoi(e) : 1; }();
+int g_ln_rows = [] { const char* e = getenv("DSIM_LN_ROWS"); return e ? atoi(e) : 1; }();
 namespace {
 
 constexpr int GN_THREADS = 256;
@@ -130,18 +131,43 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
         }
     }
     __syncthreads();
-    // one thread per group, fixed summation order, f64
-    if (tid < groups) {
+    // GN_THREADS / gp2 threads per group (gp2 = groups rounded up to a power of two) fold a fixed strided subset of the
+    // group's R x cpg partials in f64, then a fixed xor-shuffle tree: same order for a given shape, and no single thread
+    // walking the whole list while the workgroup waits
+    int gp2 = 1;
+    while (gp2 < groups) gp2 *= 2;
+    const int tg = GN_THREADS / gp2;                           // >= 4 (groups <= 64)
+    {
         const int cpg = C / groups;
+        const int g = tid / tg, t = tid - g * tg, cnt = R * cpg;
         double a = 0.0, q = 0.0;
-        for (int rr = 0; rr < R; ++rr)
-            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
-                a += (double)lds[((size_t)rr * C + c) * 2 + 0];
-                q += (double)lds[((size_t)rr * C + c) * 2 + 1];
+        if (g < groups)
+            for (int i = t; i < cnt; i += tg) {
+                const int rr = i / cpg, c = g * cpg + (i - rr * cpg);
+                const float2 pr = *reinterpret_cast<const float2*>(&lds[((size_t)rr * C + c) * 2]);
+                a += (double)pr.x;
+                q += (double)pr.y;
             }
-        double* o = part + (((size_t)b * chunks + chunk) * groups + tid) * 2;
-        o[0] = a;
-        o[1] = q;
+        for (int off = tg >> 1; off > 0; off >>= 1) {          // tg <= 64 whenever groups >= 4; wider: see below
+            if (off < 64) {
+                a += __shfl_xor(a, off, 64);
+                q += __shfl_xor(q, off, 64);
+            }
+        }
+        if (tg > 64) {                                         // fewer than 4 groups: a group spans tg / 64 waves
+            __shared__ double s_w[4][2];
+            if ((tid & 63) == 0) { s_w[tid >> 6][0] = a; s_w[tid >> 6][1] = q; }
+            __syncthreads();
+            if (t == 0) {
+                a = 0.0; q = 0.0;
+                for (int k = 0; k < tg / 64; ++k) { a += s_w[g * (tg / 64) + k][0]; q += s_w[g * (tg / 64) + k][1]; }
+            }
+        }
+        if (t == 0 && g < groups) {
+            double* o = part + (((size_t)b * chunks + chunk) * groups + g) * 2;
+            o[0] = a;
+            o[1] = q;
+        }
     }
 }
 
@@ -175,18 +201,25 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restric
         for (int i = tid; i < cnt; i += GN_THREADS) fold[i] = src[i];
     }
     __syncthreads();
-    if (tid < groups) {
+    {
+        // 4 threads per group (groups <= 64) take every 4th chunk, then a two-step xor-shuffle: fixed order per shape
+        const int g = tid >> 2, t = tid & 3;
         double a = 0.0, q = 0.0;
-        for (int c = 0; c < chunks; ++c) {
-            a += fold[(c * groups + tid) * 2];
-            q += fold[(c * groups + tid) * 2 + 1];
+        if (g < groups)
+            for (int c = t; c < chunks; c += 4) {
+                a += fold[(c * groups + g) * 2];
+                q += fold[(c * groups + g) * 2 + 1];
+            }
+        a += __shfl_xor(a, 2, 64); q += __shfl_xor(q, 2, 64);
+        a += __shfl_xor(a, 1, 64); q += __shfl_xor(q, 1, 64);
+        if (t == 0 && g < groups) {
+            const double n = (double)HW * cpg;
+            const double mean = a / n;
+            double var = q / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            s_mean[g] = (float)mean;
+            s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
         }
-        const double n = (double)HW * cpg;
-        const double mean = a / n;
-        double var = q / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        s_mean[tid] = (float)mean;
-        s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
     }
     __syncthreads();
     if (trow >= R) return;
@@ -331,6 +364,95 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+// Affine LayerNorm with LPR lanes per row (LPR = the largest power of two dividing the row's S 16-byte chunks, CPL = S / LPR
+// chunks per lane): a wave pass covers 64 / LPR rows with all 64 lanes busy, lane s of a row owning chunks s, s + LPR, ... so
+// every load instruction reads runs of LPR * 16 contiguous bytes.  C = 320 (40 chunks) keeps 8 lanes x 5 chunks per row
+// instead of 40 of 64 lanes and a six-step cross-lane reduction per row: 2.4x fewer VALU instructions per byte, which is
+// what bounded the wave-per-row form at the 64 x 64 level.  gamma / beta sit in LDS; the next pass's rows are in flight
+// while the current pass is reduced.  Two-pass statistics (mean, then centred squares), fixed order per shape.
+template <typename T, int CPL>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, T* __restrict__ out,
+                                                             int M, int C, float eps, int LPR, int passes) {
+    constexpr int VEC = Vec16<T>::N;
+    typedef typename Vec16<T>::type V;
+    extern __shared__ __attribute__((aligned(16))) char smem_ln[];
+    float* s_g = reinterpret_cast<float*>(smem_ln);
+    float* s_b = s_g + C;
+    for (int i = threadIdx.x; i < C; i += 256) { s_g[i] = gamma[i]; s_b[i] = beta[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rpw = 64 / LPR;                                  // rows per wave pass
+    const int sub = lane & (LPR - 1), rl = lane / LPR;
+    const int base = (blockIdx.x * 4 + wave) * passes * rpw;
+    if (base >= M) return;
+    const float invC = 1.0f / (float)C;
+    V t[CPL], tn[CPL];
+    {
+        const int row = base + rl < M ? base + rl : M - 1;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) t[k] = *reinterpret_cast<const V*>(x + (size_t)row * C + (sub + LPR * k) * VEC);
+    }
+    for (int p = 0; p < passes; ++p) {
+        const int row = base + p * rpw + rl;
+        if (base + p * rpw >= M) break;                        // wave-uniform
+        if (p + 1 < passes) {
+            const int nr = row + rpw < M ? row + rpw : M - 1;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) tn[k] = *reinterpret_cast<const V*>(x + (size_t)nr * C + (sub + LPR * k) * VEC);
+        }
+        float v[CPL][VEC];
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { v[k][e] = (float)t[k][e]; sum += v[k][e]; }
+        if (LPR > 32) sum += __shfl_xor(sum, 32);
+        if (LPR > 16) sum += __shfl_xor(sum, 16);
+        if (LPR > 8) sum += __shfl_xor(sum, 8);
+        if (LPR > 4) sum += __shfl_xor(sum, 4);
+        if (LPR > 2) sum += __shfl_xor(sum, 2);
+        if (LPR > 1) sum += __shfl_xor(sum, 1);
+        const float mean = sum * invC;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { v[k][e] -= mean; sq = fmaf(v[k][e], v[k][e], sq); }
+        if (LPR > 32) sq += __shfl_xor(sq, 32);
+        if (LPR > 16) sq += __shfl_xor(sq, 16);
+        if (LPR > 8) sq += __shfl_xor(sq, 8);
+        if (LPR > 4) sq += __shfl_xor(sq, 4);
+        if (LPR > 2) sq += __shfl_xor(sq, 2);
+        if (LPR > 1) sq += __shfl_xor(sq, 1);
+        const float rstd = 1.0f / sqrtf(sq * invC + eps);
+        if (row < M) {
+            T* orow = out + (size_t)row * C;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const int c = (sub + LPR * k) * VEC;
+                V o;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o[e] = (T)fmaf(v[k][e] * rstd, s_g[c + e], s_b[c + e]);
+                *reinterpret_cast<V*>(orow + c) = o;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) t[k] = tn[k];
+    }
+}
+
+template <typename T, int CPL>
+void ln_rows_launch(const void* x, const float* gamma, const float* beta, void* out, int M, int C, float eps, int LPR,
+                    hipStream_t s) {
+    const int rpw = 64 / LPR;
+    int passes = 4;                                             // rows per workgroup = 4 waves x passes x rpw
+    while (passes > 1 && (M + 4 * passes * rpw - 1) / (4 * passes * rpw) < 2048) passes >>= 1;
+    const int blocks = (M + 4 * passes * rpw - 1) / (4 * passes * rpw);
+    hipLaunchKernelGGL((layernorm_rows_kernel<T, CPL>), dim3(blocks), dim3(256), (size_t)2 * C * sizeof(float), s,
+                       (const T*)x, gamma, beta, (T*)out, M, C, eps, LPR, passes);
+}
+
 template <typename T, bool MOD>
 int ln_typed(const void* x, const float* gamma, const float* beta, void* out, int M, int C, float eps, int rpb,
              hipStream_t s) {
@@ -338,6 +460,21 @@ int ln_typed(const void* x, const float* gamma, const float* beta, void* out, in
     if (C % VEC || C > 64 * 6 * VEC || M < 1) return DSIM_ERR_INVALID;
     const int S = C / VEC;
     const dim3 block(256);
+    if (!MOD && g_ln_rows && S <= 80) {      // wider rows: the wave-per-row form below already streams at > 6 TB/s
+        int LPR = 1;
+        while (LPR < 64 && S % (LPR * 2) == 0) LPR *= 2;
+        const int CPL = S / LPR;
+        bool done = true;
+        switch (CPL) {
+            case 1: ln_rows_launch<T, 1>(x, gamma, beta, out, M, C, eps, LPR, s); break;
+            case 2: ln_rows_launch<T, 2>(x, gamma, beta, out, M, C, eps, LPR, s); break;
+            case 3: ln_rows_launch<T, 3>(x, gamma, beta, out, M, C, eps, LPR, s); break;
+            case 4: ln_rows_launch<T, 4>(x, gamma, beta, out, M, C, eps, LPR, s); break;
+            case 5: ln_rows_launch<T, 5>(x, gamma, beta, out, M, C, eps, LPR, s); break;
+            default: done = false;
+        }
+        if (done) { DSIM_HIP_CHECK(hipGetLastError()); return DSIM_OK; }
+    }
     if (S <= 64)
         hipLaunchKernelGGL((layernorm_kernel<T, MOD, 1, 8>), dim3((M + 31) / 32), block, 0, s, (const T*)x, gamma, beta,
                            (T*)out, M, C, eps, rpb);
@@ -453,20 +590,43 @@ __global__ __launch_bounds__(GN_THREADS) void gn_onepass_kernel(const T* __restr
         }
     }
     __syncthreads();
-    const int gslab = CS / cpg;                                // whole groups in this slab
-    if (tid < gslab) {
+    // fold of a group's R x cpg channel partials in f64: tg = GN_THREADS / gslab threads per group take a fixed strided
+    // subset each, then a fixed xor-shuffle tree (and, for groups wider than a wave, a last serial fold of the per-wave
+    // sums).  The order depends on the shape only.  (One thread per group walking the list serially held the whole
+    // workgroup -- and, with every workgroup of the launch in the same phase, the chip -- for several microseconds.)
+    const int gslab = CS / cpg;                                // whole groups in this slab (a power of two)
+    const int tg = GN_THREADS / gslab;                         // threads per group: 8 .. 256
+    {
+        const int g = tid / tg, t = tid - g * tg, cnt = R * cpg;
         double a = 0.0, q = 0.0;
-        for (int rr = 0; rr < R; ++rr)
-            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
-                a += (double)lds[((size_t)rr * CS + c) * 2 + 0];
-                q += (double)lds[((size_t)rr * CS + c) * 2 + 1];
+        for (int i = t; i < cnt; i += tg) {
+            const int rr = i / cpg, c = g * cpg + (i - rr * cpg);
+            const float2 pr = *reinterpret_cast<const float2*>(&lds[((size_t)rr * CS + c) * 2]);
+            a += (double)pr.x;
+            q += (double)pr.y;
+        }
+        const int w = tg < 64 ? tg : 64;
+        for (int off = w >> 1; off > 0; off >>= 1) {
+            a += __shfl_xor(a, off, 64);
+            q += __shfl_xor(q, off, 64);
+        }
+        __shared__ double s_wsum[4][2];                        // per-wave sums when a group spans several waves
+        if (tg > 64) {
+            if ((tid & 63) == 0) { s_wsum[tid >> 6][0] = a; s_wsum[tid >> 6][1] = q; }
+            __syncthreads();
+            if (t == 0) {
+                a = 0.0; q = 0.0;
+                for (int k = 0; k < tg / 64; ++k) { a += s_wsum[g * (tg / 64) + k][0]; q += s_wsum[g * (tg / 64) + k][1]; }
             }
-        const double n = (double)HW * cpg;
-        const double mean = a / n;
-        double var = q / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        s_mean[tid] = (float)mean;
-        s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        if (t == 0) {
+            const double n = (double)HW * cpg;
+            const double mean = a / n;
+            double var = q / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            s_mean[g] = (float)mean;
+            s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+        }
     }
     __syncthreads();
     if (!live) return;
@@ -502,7 +662,9 @@ int gn_onepass_slab(int C0, int C1, int B, int HW, int groups) {
     constexpr int VEC = Vec16<T>::N;
     const int C = C0 + C1, cpg = C / groups;
     // The choice depends on the SHAPE only, never on the batch: slab width sets the summation grouping, and a batch of N
-    // must score bit for bit like N single images.  Widest legal slab = longest coalesced row segments.
+    // must score bit for bit like N single images.  The narrowest legal slab, widened while a thread still holds at most
+    // 8 chunks: wider slabs mean longer coalesced row segments but fewer, longer-running workgroups (the 8 x 8 level with
+    // 640-channel slabs ran 2 workgroups per image at 2.5 TB/s).
     (void)B;
     int best = 0;
     for (int gs = 1; gs <= groups; gs *= 2) {                  // groups per slab
@@ -514,7 +676,7 @@ int gn_onepass_slab(int C0, int C1, int B, int HW, int groups) {
         const int tpr = CS / VEC, R = GN_THREADS / tpr;
         if ((HW + R - 1) / R > GN_OP_MAXCH) continue;
         if ((size_t)R * CS * 2 * sizeof(float) > 48 * 1024) continue;
-        best = CS;
+        if (!best || (HW + R - 1) / R <= 8) best = CS;
     }
     return best;
 }

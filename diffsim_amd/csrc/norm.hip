@@ -463,13 +463,11 @@ int ln_typed(const void* x, const float* gamma, const float* beta, void* out, in
     if (!MOD && g_ln_rows && S <= 80) {      // wider rows: the wave-per-row form below already streams at > 6 TB/s
         int LPR = 1;
         while (LPR < 64 && S % (LPR * 2) == 0) LPR *= 2;
-        const int CPL = S / LPR;
+        const int CPL = S / LPR;                       // odd by construction
         bool done = true;
         switch (CPL) {
             case 1: ln_rows_launch<T, 1>(x, gamma, beta, out, M, C, eps, LPR, s); break;
-            case 2: ln_rows_launch<T, 2>(x, gamma, beta, out, M, C, eps, LPR, s); break;
             case 3: ln_rows_launch<T, 3>(x, gamma, beta, out, M, C, eps, LPR, s); break;
-            case 4: ln_rows_launch<T, 4>(x, gamma, beta, out, M, C, eps, LPR, s); break;
             case 5: ln_rows_launch<T, 5>(x, gamma, beta, out, M, C, eps, LPR, s); break;
             default: done = false;
         }

@@ -124,7 +124,25 @@ def test_groupnorm(eng, dtype, B, HW, C0, C1, silu, eps):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,C", [(257, 320), (64, 1280), (100, 64), (33, 640)])
+@pytest.mark.parametrize("B,HW,C,groups", [(2, 300, 64, 2), (3, 128, 96, 3), (2, 256, 512, 8), (2, 64, 1024, 1), (2, 1024, 384, 48)])
+def test_groupnorm_group_counts(eng, dtype, B, HW, C, groups):
+    """Group counts other than 32: the statistics folds split 256 threads over the groups (a group wider than a wave, a
+    count that is not a power of two, one group, more groups than a wave has quarter-rows)."""
+    g = torch.Generator().manual_seed(HW + C + groups)
+    x = torch.randn(B, HW, C, generator=g) * 1.5 - 0.4
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    want = F.group_norm(_q(x, dtype).permute(0, 2, 1), groups, gamma, beta, 1e-5).permute(0, 2, 1)
+    got = eng.op_groupnorm(_dev(x, dtype), None, _dev(gamma), _dev(beta), groups, 1e-5, False)
+    _close(got, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C", [
+    (257, 320), (64, 1280), (100, 64), (33, 640),
+    # the lanes-per-row form (rows up to 80 16-byte chunks): 1 / 3 / 5 chunks per lane, 4 .. 64 lanes per row, ragged row counts,
+    # and row counts large enough for 2 and 4 passes per wave
+    (1000, 192), (77, 96), (513, 160), (130, 256), (65, 512), (140001, 320), (262200, 64)])
 def test_layernorm(eng, dtype, M, C):
     g = torch.Generator().manual_seed(M + C)
     x = torch.randn(M, C, generator=g) * 3 + 1

@@ -227,7 +227,8 @@ def test_pair_score_batched_indices_and_determinism(eng):
                                        (128 * 1100 + 5, 160, 64, False),      # 128x160 tiles, 1101 tiles > 512 WGs
                                        (256 * 300 + 1, 512, 128, True),       # 256x256 tiles, 2 column tiles
                                        (256 * 280 + 9, 1152, 128, True),      # 256x192 tiles (DiT widths), 6 column tiles
-                                       (256 * 260, 384, 192, False)])         # 256x192, plain epilogue
+                                       (256 * 260, 384, 192, False),         # 256x192, plain epilogue
+                                       (256 * 40 + 3, 3456, 128, True)])      # DiT qkv width: 256x256 tiles, ragged 14th column tile
 def test_linear_many_tiles_per_workgroup(eng, dtype, M, N, K, res):
     """Each persistent workgroup walks several tiles (stage prefetch under the epilogue, LDS buffer parity carried
     across tiles, ragged last tile): every row of the output is checked against torch on a strided sample plus the

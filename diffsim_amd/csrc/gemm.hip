@@ -391,6 +391,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
             __builtin_amdgcn_sched_barrier(0);
             // register phase: bias (f32, before the one rounding to T) and the D^T -> row-major transpose through LDS
             const bool odd_half = p.bias2 && (((mw0 + i * 32 + el31) / p.rows_per_batch) & 1);
+            const int slab_half_div = (SLOW && p.gate2) ? (mw0 + i * 32) / p.rows_per_batch : 0;
 #pragma unroll
             for (int j = 0; j < TN; j += (GEGLU ? 2 : 1)) {
 #pragma unroll
@@ -456,16 +457,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                 for (int e = 0; e < VEC; ++e) v[e] = (float)t[e];
                 if (SLOW && p.act == 1) {
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) {      // tanh-GELU: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
-                        const float x = v[e], u = 0.7978845608028654f * fmaf(0.044715f * x * x, x, x);
-                        const float ex = __builtin_amdgcn_exp2f(2.8853900817779268f * u);      // e^(2u)
-                        v[e] = 0.5f * x * (1.0f + (1.0f - 2.0f / (ex + 1.0f)));
+                    for (int e = 0; e < VEC; ++e) {
+                        // tanh-GELU: 0.5 x (1 + tanh(u)) = x / (1 + e^(-2u)), u = sqrt(2/pi) (x + 0.044715 x^3); with the
+                        // constants folded -2u log2(e) = x (a + b x^2): 5 plain VALU + v_exp + v_rcp per element (an IEEE
+                        // divide alone expands to ~10 instructions, and this epilogue is issue-bound)
+                        const float x = v[e];
+                        const float t = x * fmaf(-0.10294324f, x * x, -2.3022082f);
+                        v[e] = x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
                     }
                 }
                 if (SLOW && p.gate) {
                     const int m = mw0 + i * 32 + rrow, ncol = nout0 + c * VEC;
                     if (ncol < Nout) {
-                        const float* gsel = (p.gate2 && ((m / p.rows_per_batch) & 1)) ? p.gate2 : p.gate;
+                        // which CFG half the row belongs to: one division per 32-row slab when the halves are 32-row
+                        // aligned (every production shape), per row otherwise
+                        const bool odd = p.gate2 && ((((p.rows_per_batch & 31) == 0 ? slab_half_div : m / p.rows_per_batch)) & 1);
+                        const float* gsel = odd ? p.gate2 : p.gate;
 #pragma unroll
                         for (int e = 0; e < VEC; e += 4) {
                             const f32x4 g4 = *reinterpret_cast<const f32x4*>(gsel + ncol + e);

@@ -1,5 +1,7 @@
 """Development probe: ablation timing of linear GEMM shapes (HIP events over 20 launches) under the DSIM_DBG hooks
-(1 no MFMA, 2 stores dropped, 4 residual loads short-circuited, 8 A loads short-circuited, 16 W loads short-circuited)."""
+(1 no MFMA, 2 stores dropped, 4 residual loads short-circuited, 8 A loads short-circuited, 16 W loads short-circuited).
+The hooks are NOT in the tree: apply the patch at the end of profiles/r02_linear_ablation.txt to gemm.hip / common.h first
+(without it every mask times the unmodified kernel)."""
 import os
 import sys
 import torch

@@ -4,6 +4,7 @@
 #include "common.h"
 
 namespace dsim {
+int g_prep8 = [] { const char* e = getenv("DSIM_PREP8"); return e ? atoi(e) : 1; }();
 namespace {
 
 __device__ __forceinline__ float ld_any(const void* p, int dt, size_t i) {
@@ -175,6 +176,78 @@ __global__ __launch_bounds__(256) void prep_conv_in_kernel(const float* __restri
     }
 }
 
+// The same direct conv with 16-byte stores: a thread owns 8 consecutive output channels of PP pixels (lanes of a pixel
+// group cover that pixel's whole channel row, so every store instruction writes full rows), weights come as two float4 per
+// tap.  Each output still sums its taps in ascending k order: bit-identical to prep_conv_in_kernel.  Needs Cout % 8 == 0 and
+// Cout <= 2048.  The one-channel-per-thread kernel issued a 2-byte store per (pixel, copy) per lane and ran at 1.2 TB/s.
+template <typename T, int PP>
+__global__ __launch_bounds__(256) void prep_conv_in8_kernel(const float* __restrict__ lat, const float* __restrict__ noise,
+                                                            float sa, float sb, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, T* __restrict__ out, int Cin,
+                                                            int S, int Cout, int dup) {
+    extern __shared__ float patch[];                // [npg * PP][9*Cin]
+    const int CG = Cout / 8, npg = 256 / CG, PIX = npg * PP;
+    const int img = blockIdx.y, p0 = blockIdx.x * PIX, K = 9 * Cin, HW = S * S;
+    for (int i = threadIdx.x; i < PIX * K; i += 256) {
+        const int pp = i / K, k = i - pp * K;
+        const int tap = k / Cin, ci = k - tap * Cin;
+        const int pix = p0 + pp;
+        float v = 0.f;
+        if (pix < HW) {
+            const int y = pix / S + tap / 3 - 1, x = pix % S + tap % 3 - 1;
+            if ((unsigned)y < (unsigned)S && (unsigned)x < (unsigned)S) {
+                const size_t o = (((size_t)img * Cin + ci) * S + y) * S + x;
+                v = noise ? sa * lat[o] + sb * noise[o] : lat[o];
+            }
+        }
+        patch[i] = v;
+    }
+    __syncthreads();
+    const int cg = threadIdx.x % CG, pg = threadIdx.x / CG;
+    if (pg >= npg) return;
+    const int co = cg * 8;
+    float acc[PP][8];
+    {
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + co), b1 = *reinterpret_cast<const float4*>(bias + co + 4);
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) {
+            acc[pp][0] = b0.x; acc[pp][1] = b0.y; acc[pp][2] = b0.z; acc[pp][3] = b0.w;
+            acc[pp][4] = b1.x; acc[pp][5] = b1.y; acc[pp][6] = b1.z; acc[pp][7] = b1.w;
+        }
+    }
+    const float* prow = patch + (size_t)pg * PP * K;
+    for (int k = 0; k < K; ++k) {
+        const float4 w0 = *reinterpret_cast<const float4*>(w + (size_t)k * Cout + co);
+        const float4 w1 = *reinterpret_cast<const float4*>(w + (size_t)k * Cout + co + 4);
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) {
+            const float pv = prow[pp * K + k];
+            acc[pp][0] = fmaf(pv, w0.x, acc[pp][0]); acc[pp][1] = fmaf(pv, w0.y, acc[pp][1]);
+            acc[pp][2] = fmaf(pv, w0.z, acc[pp][2]); acc[pp][3] = fmaf(pv, w0.w, acc[pp][3]);
+            acc[pp][4] = fmaf(pv, w1.x, acc[pp][4]); acc[pp][5] = fmaf(pv, w1.y, acc[pp][5]);
+            acc[pp][6] = fmaf(pv, w1.z, acc[pp][6]); acc[pp][7] = fmaf(pv, w1.w, acc[pp][7]);
+        }
+    }
+#pragma unroll
+    for (int pp = 0; pp < PP; ++pp) {
+        const int pix = p0 + pg * PP + pp;
+        if (pix >= HW) continue;
+        for (int d = 0; d < dup; ++d) {
+            T* o = out + ((size_t)(img * dup + d) * HW + pix) * Cout + co;
+            if constexpr (sizeof(T) == 2) {
+                bf16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)acc[pp][e];
+                *reinterpret_cast<bf16x8*>(o) = v;
+            } else {
+                f32x4 v0 = {acc[pp][0], acc[pp][1], acc[pp][2], acc[pp][3]}, v1 = {acc[pp][4], acc[pp][5], acc[pp][6], acc[pp][7]};
+                *reinterpret_cast<f32x4*>(o) = v0;
+                *reinterpret_cast<f32x4*>(o + 4) = v1;
+            }
+        }
+    }
+}
+
 __global__ void convert_kernel(const float* src, void* dst, int ddt, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) st_any(dst, ddt, i, src[i]);
@@ -229,6 +302,22 @@ int sincos_values(float* out, int dim, const float* vals, int count, hipStream_t
 }
 int prep_conv_in(const float* lat, const float* noise, float sa, float sb, const float* w, const float* bias, void* out,
                  int dtype, int n_img, int Cin, int S, int Cout, int dup, hipStream_t st) {
+    if (g_prep8 && Cout % 8 == 0 && Cout / 8 <= 256) {
+        constexpr int PP = 4;
+        const int PIX = (256 / (Cout / 8)) * PP;
+        const dim3 grid8((S * S + PIX - 1) / PIX, n_img);
+        const size_t lds8 = (size_t)PIX * 9 * Cin * sizeof(float);
+        if (lds8 <= 48 * 1024) {
+            if (dtype == DSIM_BF16)
+                hipLaunchKernelGGL((prep_conv_in8_kernel<bf16, PP>), grid8, dim3(256), lds8, st, lat, noise, sa, sb, w, bias, (bf16*)out, Cin, S, Cout, dup);
+            else if (dtype == DSIM_F32)
+                hipLaunchKernelGGL((prep_conv_in8_kernel<float, PP>), grid8, dim3(256), lds8, st, lat, noise, sa, sb, w, bias, (float*)out, Cin, S, Cout, dup);
+            else
+                return DSIM_ERR_INVALID;
+            DSIM_HIP_CHECK(hipGetLastError());
+            return DSIM_OK;
+        }
+    }
     const dim3 grid((S * S + PREP_PIX - 1) / PREP_PIX, n_img), block(256);
     const size_t lds = (size_t)PREP_PIX * 9 * Cin * sizeof(float);
     if (dtype == DSIM_BF16)

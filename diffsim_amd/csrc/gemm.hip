@@ -306,6 +306,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int NIT = (32 * CPR + 63) / 64;          // read-back iterations per 32-row slab
     constexpr bool SLOW = EK == EK_SLOW;
+    // linear layers start their accumulators at the bias (see the tile loop); the 3x3 conv keeps the bias add in its epilogue
+    // (its K loop is long enough that the epilogue's loads do not matter, and the changed register allocation cost it 2.5 %)
+    constexpr bool BIAS_INIT = MODE == GEMM_LINEAR;
     const bool has_res = EK == EK_RES || (SLOW && p.epi == EPI_RESIDUAL);
 
     int vb = blockIdx.x;
@@ -313,12 +316,41 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     setup(vb);
     stage(0, 0);
     while (true) {
+        // The accumulators start at the bias (f32) of their output column instead of zero: the epilogue then has no bias
+        // work at all.  (It used to fetch the bias in its register phase: 40 dependent global loads per tile, each followed
+        // by a vmcnt(0) that also drained the next tile's first stage and the residual prefetch.)  Here the 20 loads of a
+        // tile fly while stage 0 lands.  D^T layout: register r of block j is column n0 + wn*WBN + 32 j + 8 (r>>2) + 4 half + (r&3).
+        if (BIAS_INIT && p.bias) {
+            int ilane = lane;
+            asm volatile("" : "+v"(ilane));                     // per-tile lane id: nothing derived from it stays live in the K loop
+            const int ihalf = ilane >> 5, il31 = ilane & 31;
+            bool odd[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
+                odd[i] = p.bias2 && (((m0 + wm * (BM / WM) + i * 32 + il31) / p.rows_per_batch) & 1);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                for (int g = 0; g < 4; ++g) {
+                    const int nb = n0 + wn * WBN + j * 32 + 8 * g + 4 * ihalf;
+                    f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, c4 = {0.f, 0.f, 0.f, 0.f};
+                    if (nb < p.N) {
+                        b4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
+                        if (p.bias2) c4 = *reinterpret_cast<const f32x4*>(p.bias2 + nb);
+                    }
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = odd[i] ? c4[e] : b4[e];
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        }
         // stage 0 has landed in every wave; every wave is past the previous tile's epilogue (its LDS slabs are free)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -389,9 +421,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
             __builtin_amdgcn_sched_barrier(0);      // keep slab i+1's loads from being hoisted above slab i (spills)
             if (has_res) prefetch(i, 0, PF0);
             __builtin_amdgcn_sched_barrier(0);
-            // register phase: bias (f32, before the one rounding to T) and the D^T -> row-major transpose through LDS
-            const bool odd_half = p.bias2 && (((mw0 + i * 32 + el31) / p.rows_per_batch) & 1);
             const int slab_half_div = (SLOW && p.gate2) ? (mw0 + i * 32) / p.rows_per_batch : 0;
+            const bool odd_half = !BIAS_INIT && p.bias2 && (((mw0 + i * 32 + el31) / p.rows_per_batch) & 1);
+            // register phase: the D^T -> row-major transpose through LDS (linear mode: the bias is already in the accumulators)
 #pragma unroll
             for (int j = 0; j < TN; j += (GEGLU ? 2 : 1)) {
 #pragma unroll
@@ -399,15 +431,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                     float v[4];
                     if (GEGLU) {
                         // packed weight rows alternate 32-row blocks [h-block, g-block]
-                        const int nh = nw0 + j * 32 + 8 * g + 4 * ehalf;
-                        f32x4 bh = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
-                        if (p.bias && nh < p.N) {
-                            bh = *reinterpret_cast<const f32x4*>(p.bias + nh);
-                            bg = *reinterpret_cast<const f32x4*>(p.bias + nh + 32);
-                        }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            v[e] = (acc[i][j][4 * g + e] + bh[e]) * gelu_erf(acc[i][j + 1][4 * g + e] + bg[e]);
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * gelu_erf(acc[i][j + 1][4 * g + e]);
+                    } else if (BIAS_INIT) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
                     } else {
                         const int nb = nw0 + j * 32 + 8 * g + 4 * ehalf;
                         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};

@@ -129,9 +129,10 @@ constexpr int gemm_spare_bytes() {
     const int stage = (BM + BN) * 128, epi = gemm_epi_bytes<T, BM, BN, GEGLU, WM, WN>();
     return epi > stage ? ((epi - stage + 1023) / 1024) * 1024 : 0;
 }
+// + two f32 bias slices of the tile's BN columns (the conv epilogue reads its bias from LDS; buffer = tile parity)
 template <typename T, int BM, int BN, bool GEGLU, int WM, int WN>
 constexpr int gemm_lds_bytes() {
-    return 2 * (BM + BN) * 128 + gemm_spare_bytes<T, BM, BN, GEGLU, WM, WN>();
+    return 2 * (BM + BN) * 128 + gemm_spare_bytes<T, BM, BN, GEGLU, WM, WN>() + 2 * BN * 4;
 }
 
 // WM x WN waves; each owns a (BM/WM) x (BN/WN) sub-tile, so an A fragment is reused by BN/WN/32 MFMAs and
@@ -312,10 +313,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     const bool has_res = EK == EK_RES || (SLOW && p.epi == EPI_RESIDUAL);
 
     int vb = blockIdx.x;
+    int tile_par = 0;                                   // parity of this workgroup's tile counter (bias buffer)
     int b0 = 0;                                         // staging buffer holding K stage 0 of the current tile
     setup(vb);
     stage(0, 0);
     while (true) {
+        // 3x3 conv: the tile's bias slice goes to LDS here (80 lanes, one float4 each); the epilogue's register phase then reads
+        // it with ds_read_b128 instead of 40 dependent global loads per tile, each behind a vmcnt(0) that also waited for the
+        // next tile's first stage.  Buffer = tile parity: a wave is at most one tile ahead of the slowest (the barrier below).
+        // (bias2, the per-CFG-half bias of SDXL's resnets, keeps the global path.)
+        float* const bias_lds = reinterpret_cast<float*>(smem + 2 * STAGE + SPARE) + (tile_par ? BN : 0);
+        const bool bias_in_lds = !BIAS_INIT && p.bias && !p.bias2;
+        if (bias_in_lds && tid < BN / 4) {
+            const int n = n0 + tid * 4;
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (n < p.N) b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            *reinterpret_cast<f32x4*>(bias_lds + tid * 4) = b4;
+        }
         // The accumulators start at the bias (f32) of their output column instead of zero: the epilogue then has no bias
         // work at all.  (It used to fetch the bias in its register phase: 40 dependent global loads per tile, each followed
         // by a vmcnt(0) that also drained the next tile's first stage and the residual prefetch.)  Here the 20 loads of a
@@ -439,7 +453,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                     } else {
                         const int nb = nw0 + j * 32 + 8 * g + 4 * ehalf;
                         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-                        if (p.bias && nb < p.N) {
+                        if (bias_in_lds) {
+                            b4 = *reinterpret_cast<const f32x4*>(bias_lds + (nb - en0));
+                        } else if (p.bias && nb < p.N) {
                             b4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
                             if (p.bias2) {
                                 const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.bias2 + nb);
@@ -524,6 +540,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
         // the staging state was dead during the epilogue (registers!): re-derive it for the K loop.  The opaque
         // copy keeps the compiler from holding the pre-epilogue values live across the epilogue instead.
         vb = nvb;
+        tile_par ^= 1;
         asm volatile("" : "+s"(vb));
         setup(vb);
         derive(0);

@@ -48,7 +48,8 @@ def rocprof_name(fam: str) -> str:
         mode = "1" if p[3] == "conv3" else "0"
         geglu = "true" if fam.endswith("_geglu") else "false"
         wn = "2" if bm == "256" else "1"          # 256-row tiles run 8 waves as 4x2, 128-row tiles 4x1
-        ek = "1" if fam.endswith("_res") else ("2" if fam.endswith("_dit") else "0")   # epilogue kind: plain / residual / DiT act+gate
+        # epilogue kind: plain / residual / DiT gate(+act, +residual) / DiT tanh-GELU only
+        ek = "1" if fam.endswith("_res") else ("2" if fam.endswith("_dit") else ("3" if fam.endswith("_act") else "0"))
         return f"gemm_kernel<{t}, {bm}, {bn}, {mode}, {geglu}, 4, {wn}, {ek}>"
     if p[0] == "attention":
         if p[1] == "fp8":

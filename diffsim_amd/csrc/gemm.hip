@@ -144,7 +144,7 @@ constexpr int gemm_lds_bytes() {
 // EK (epilogue kind): EK_PLAIN bias only; EK_RES + residual; EK_SLOW the DiT epilogues (tanh-GELU activation, adaLN
 // gate, optional residual decided at run time).  Compile-time, because a run-time residual flag makes hipcc keep
 // every prefetched residual register in scratch, and the DiT math would add its register pressure to all users.
-enum { EK_PLAIN = 0, EK_RES = 1, EK_SLOW = 2 };
+enum { EK_PLAIN = 0, EK_RES = 1, EK_SLOW = 2, EK_ACT = 3 };   // EK_ACT: tanh-GELU only (DiT Mlp.fc1): no gate, no residual registers
 template <typename T, int BM, int BN, int MODE, bool GEGLU, int WM, int WN, int EK>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p, const int tilesN, const int ntiles) {
     constexpr int NW = WM * WN;
@@ -307,6 +307,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int NIT = (32 * CPR + 63) / 64;          // read-back iterations per 32-row slab
     constexpr bool SLOW = EK == EK_SLOW;
+    constexpr bool ACT = EK == EK_ACT;
     // linear layers start their accumulators at the bias (see the tile loop); the 3x3 conv keeps the bias add in its epilogue
     // (its K loop is long enough that the epilogue's loads do not matter, and the changed register allocation cost it 2.5 %)
     constexpr bool BIAS_INIT = MODE == GEMM_LINEAR;
@@ -492,14 +493,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                 // rows beyond the slab (idx >= 32*CPR) read a neighbouring wave's LDS slab; their store is dropped
                 const int rrow = row < 32 ? row : 31;
                 const V16 t = *reinterpret_cast<const V16*>(wst + rrow * RSO + c * 16);
-                if (!SLOW && !has_res) {                 // plain projection: LDS -> HBM copy
+                if (!SLOW && !ACT && !has_res) {         // plain projection: LDS -> HBM copy
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rO, (int)off, 0, 0);
                     continue;
                 }
                 float v[VEC];
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) v[e] = (float)t[e];
-                if (SLOW && p.act == 1) {
+                if (ACT || (SLOW && p.act == 1)) {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
                         // tanh-GELU: 0.5 x (1 + tanh(u)) = x / (1 + e^(-2u)), u = sqrt(2/pi) (x + 0.044715 x^3); with the
@@ -599,7 +600,10 @@ int launch_ek(const GemmArgs& a, hipStream_t s) {
 
 template <typename T, int BM, int BN, int MODE, bool GEGLU, int WM = 4, int WN = 1, bool SLOW = false>
 int launch_one(const GemmArgs& a, hipStream_t s) {
-    if constexpr (SLOW) return launch_ek<T, BM, BN, MODE, GEGLU, WM, WN, EK_SLOW>(a, s);
+    if constexpr (SLOW) {
+        if (a.act == 1 && !a.gate && a.epi != EPI_RESIDUAL) return launch_ek<T, BM, BN, MODE, GEGLU, WM, WN, EK_ACT>(a, s);
+        return launch_ek<T, BM, BN, MODE, GEGLU, WM, WN, EK_SLOW>(a, s);
+    }
     if constexpr (!GEGLU)
         if (a.epi == EPI_RESIDUAL) return launch_ek<T, BM, BN, MODE, GEGLU, WM, WN, EK_RES>(a, s);
     return launch_ek<T, BM, BN, MODE, GEGLU, WM, WN, EK_PLAIN>(a, s);

@@ -331,7 +331,7 @@ def headline(a, world, rank, dev):
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     keys = [k for k in C.unet_param_shapes(cfg) if not k.startswith(TAP_KEYS_EXCLUDE)]
     sd = S.make_state_dict(cfg, seed=0, keys=keys)
-    ds = DiffSim(torch_dtype=dtype, device=str(dev), unet_config=cfg, state_dict=sd, dedup_cfg=a.dedup_cfg)
+    ds = DiffSim(torch_dtype=dtype, device=str(dev), unet_config=cfg, state_dict=sd, dedup_cfg=a.dedup_cfg, fusion=a.fusion)
     eng = ds.engine("up_blocks", 0)
     t = sched.timestep_from_index(600)
     eng.set_timestep(t)
@@ -444,6 +444,8 @@ def main():
     ap.add_argument("--pixels-in", action="store_true",
                     help="secondary line: include the VAE encoder (512x512 pixels in HBM -> score); the headline "
                          "metric is latents-in")
+    ap.add_argument("--fusion", type=int, default=None,
+                    help="dsim_unet_set_fusion mask (default: every fused kernel; 0 = one launch per layer, for A/B)")
     ap.add_argument("--dedup-cfg", action="store_true",
                     help="secondary line: compute what the two CFG halves share (conv_in, first resnet, first self-attention) once "
                          "per image -- bit-identical scores, 6 %% fewer FLOPs executed than the algorithmic count; the headline line "

@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(HERE, "libdiffsim_amd.so")
 DSIM_F32, DSIM_BF16, DSIM_F16 = 0, 1, 2
 TAP = {"down_blocks": 0, "mid_blocks": 1, "up_blocks": 2}
 MAX_LEVELS = 4
+FUSE_FF, FUSE_ALL = 1, 1        # dsim_unet_set_fusion bits
 
 
 class DsimError(RuntimeError):
@@ -71,6 +72,7 @@ SYMBOLS = {
     "dsim_unet_set_tap": (_i, [_vp, _i, _i, _i, _i]),
     "dsim_unet_set_sample_size": (_i, [_vp, _i]),
     "dsim_unet_set_cfg_dedup": (_i, [_vp, _i]),
+    "dsim_unet_set_fusion": (_i, [_vp, _i]),
     "dsim_unet_profile": (_i, [_vp, _i]),
     "dsim_unet_profile_count": (_i, [_vp]),
     "dsim_unet_profile_get": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -101,6 +103,7 @@ SYMBOLS = {
     "dsim_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
     "dsim_op_attention": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsim_op_attention_fp8": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "dsim_op_ff_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
 
 _lib = None

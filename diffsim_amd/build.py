@@ -14,10 +14,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libdiffsim_amd.so")
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "attention_fp8.hip", "pack.hip", "unet.hip", "vae.hip", "dit.hip"]
+SOURCES = ["gemm.hip", "rowres.hip", "norm.hip", "attention.hip", "attention_fp8.hip", "pack.hip", "unet.hip", "vae.hip", "dit.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "store.h"), os.path.join(HERE, "..", "include", "diffsim_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# rowres.hip: the GELU runs beside MFMAs at one wave per SIMD, where hipcc's SLP-packed v_pk_*_f32 cost several times the two
+# scalar instructions they replace (cdna_hip_programming.md, 4-wave attention pitfalls)
+EXTRA_FLAGS = {"rowres.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target: str, deps) -> bool:
@@ -31,7 +34,7 @@ def _compile(src: str) -> str:
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
     path = os.path.join(CSRC, src)
     if _stale(obj, [path] + HEADERS):
-        cmd = [HIPCC] + FLAGS + ["-c", path, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

@@ -60,8 +60,18 @@ struct GemmArgs {
     unsigned a0_bytes = 0, a1_bytes = 0, w_bytes = 0, out_bytes = 0;   // filled by launch_gemm: operand extents for the buffer descriptors
 };
 int launch_gemm(const GemmArgs& a, int dtype, hipStream_t s);
-extern int g_gemm_persistent;
-extern int g_force_bm;     // 0 = heuristic; 128/256 force the row tile (micro-benchmark A/B only)
+// Development switches (kernel A/B in tools/kbench, environment overrides): they exist only in -DDSIM_DEVTOOLS builds
+// (tools/build_kbench.py); the product library compiles them away as constants.
+#ifdef DSIM_DEVTOOLS
+extern int g_gemm_persistent;   // 0 = one tile per workgroup
+extern int g_force_bm;          // 0 = heuristic; 128/256 force the row tile
+extern int g_gn_onepass;        // DSIM_GN_ONEPASS
+extern int g_ln_rows;           // DSIM_LN_ROWS
+extern int g_prep8;             // DSIM_PREP8
+extern int g_ff_dbg;            // ablation mask of the fused feed-forward kernel (rowres.hip)
+#else
+constexpr int g_gemm_persistent = 1, g_force_bm = 0, g_gn_onepass = 1, g_ln_rows = 1, g_prep8 = 1;
+#endif
 void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn);   // which template instantiation launch_gemm picks
 
 // weight repack kernels -- pack.hip  (src f32/bf16/f16 diffusers layout -> packed compute dtype)
@@ -118,6 +128,24 @@ int launch_pair_score(const void* q, const void* k, const void* v, const int32_t
                       const int32_t* idx_b, int n_pairs, int B, int H, int N, int D, int dtype,
                       int similarity, float* out, void* scratch, size_t scratch_bytes, hipStream_t s,
                       int32_t* status = nullptr);
+
+// row-resident fused feed-forward of the 320-channel transformer blocks (bf16) -- rowres.hip
+//   out = x + W2 (h * gelu(g)) + b2,  [h ; g] = W1 LN(x) + b1
+struct FFArgs {
+    const void* x = nullptr;                    // [M][C] bf16: LayerNorm input and residual
+    void* out = nullptr;                        // [M][C] bf16 (may alias x)
+    const float* ln_g = nullptr;
+    const float* ln_b = nullptr;
+    const void* stream = nullptr;               // pack_ff_stream output
+    const float* b1 = nullptr;                  // [8C] f32, GEGLU-interleaved (pack_vector with geglu_interleave = 1)
+    const float* b2 = nullptr;                  // [C] f32
+    int M = 0, C = 0;
+    float eps = 1e-5f;
+};
+size_t ff_stream_bytes(int C);                  // 0: no fused kernel for this width
+// w1_packed: the GEGLU-interleaved [8C][C] bf16 weight (pack_linear with geglu_interleave = 1); w2_packed: [C][4C] bf16
+int pack_ff_stream(const void* w1_packed, const void* w2_packed, void* stream, int C, hipStream_t s);
+int launch_ff_fused(const FFArgs& a, hipStream_t s);
 
 // Per-device once-flags for hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count: the attribute is a
 // per-device property of the function, so a process that drives several devices must set it on each.

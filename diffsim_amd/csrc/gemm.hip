@@ -22,8 +22,10 @@
 
 namespace dsim {
 
-int g_force_bm = 0;           // development override (kbench A/B): 128 / 256 force the row tile
-int g_gemm_persistent = 1;   // development override (kbench A/B): 0 = one tile per workgroup
+#ifdef DSIM_DEVTOOLS
+int g_force_bm = 0;
+int g_gemm_persistent = 1;
+#endif
 // Tile choice.  Small problems: 128-row tiles, 4 waves, two workgroups per CU (160-wide when N
 // allows -- every SD channel count is a multiple of 160 -- else 128).  bf16 problems with enough
 // 256-row tiles to fill the chip: 256 x 320 (or 256 x 256, or 256 x 192 for the DiT widths) tiles, 8 waves as 4 x 2.

@@ -18,8 +18,10 @@
 
 namespace dsim {
 // development A/B: DSIM_GN_ONEPASS=0 keeps the two-pass kernels at every level
+#ifdef DSIM_DEVTOOLS
 int g_gn_onepass = [] { const char* e = getenv("DSIM_GN_ONEPASS"); return e ? atoi(e) : 1; }();
 int g_ln_rows = [] { const char* e = getenv("DSIM_LN_ROWS"); return e ? atoi(e) : 1; }();
+#endif
 namespace {
 
 constexpr int GN_THREADS = 256;

@@ -4,7 +4,9 @@
 #include "common.h"
 
 namespace dsim {
+#ifdef DSIM_DEVTOOLS
 int g_prep8 = [] { const char* e = getenv("DSIM_PREP8"); return e ? atoi(e) : 1; }();
+#endif
 namespace {
 
 __device__ __forceinline__ float ld_any(const void* p, int dt, size_t i) {

@@ -31,6 +31,7 @@ struct dsim_unet : WeightStore {
     float* tscratch = nullptr;      // time-embedding scratch
     bool two_temb = false;          // SDXL: the CFG halves carry different time embeddings
     bool cfg_dedup = false;         // opt-in: compute the part of the graph that is identical in both CFG halves once
+    int fusion = DSIM_FUSE_FF;      // dsim_unet_set_fusion mask: which multi-op kernels replace their unfused chains
 };
 
 namespace {
@@ -247,7 +248,9 @@ struct Walk {
         WGET(f2w, b + "ff.net.2.weight"); WGET(f2b, b + "ff.net.2.bias");
         // self-attention
         if (!big) {
-            big = alloc_act((size_t)M * 4 * C);          // qkv [M][3C], later GEGLU out [M][4C]
+            // qkv [M][3C]; later the GEGLU output [M][4C] unless the feed-forward runs as one launch
+            const bool ff1 = h->pk.count(b + "ff.stream") && (h->fusion & DSIM_FUSE_FF);
+            big = alloc_act((size_t)M * (ff1 ? 3 : 4) * C);
             ab = alloc_act((size_t)M * C);
             kvb = alloc_act((size_t)2 * L * 2 * C);
         }
@@ -285,10 +288,26 @@ struct Walk {
             CK(attn(a));
         }
         CK(linear(big, C, nullptr, 0, o2w, o2b, hb, hb, M, C, C));
-        // feed-forward: Linear(C,8C) -> h*gelu(g) fused in the GEMM epilogue -> Linear(4C,C)
-        CK(ln(hb, l3w, l3b, nb, M, C));
-        CK(linear(nb, C, nullptr, 0, f1w, f1b, nullptr, big, M, 8 * C, 4 * C, EPI_GEGLU));
-        CK(linear(big, 4 * C, nullptr, 0, f2w, f2b, hb, hb, M, C, C));
+        // feed-forward: norm3 -> Linear(C,8C) -> h*gelu(g) -> Linear(4C,C) -> + residual.  One row-resident launch where
+        // the width has one (bf16, C = 320); else LayerNorm, the GEGLU GEMM (h*gelu(g) in its epilogue) and ff.net.2.
+        const auto fst = h->pk.find(b + "ff.stream");
+        if (fst != h->pk.end() && (h->fusion & DSIM_FUSE_FF)) {
+            if (run) {
+                FFArgs fa;
+                fa.x = hb; fa.out = hb; fa.ln_g = (const float*)l3w->p; fa.ln_b = (const float*)l3b->p;
+                fa.stream = fst->second.p; fa.b1 = (const float*)f1b->p; fa.b2 = (const float*)f2b->p; fa.M = M; fa.C = C;
+                fa.eps = 1e-5f;
+                pbegin(std::string("ff_fused_") + dtn() + "|M" + std::to_string(M) + " C" + std::to_string(C),
+                       2.0 * M * (double)C * 12 * C, 2.0 * M * (double)C * es() + 12.0 * C * C * es());
+                const int st = launch_ff_fused(fa, s);
+                pend();
+                CK(st);
+            }
+        } else {
+            CK(ln(hb, l3w, l3b, nb, M, C));
+            CK(linear(nb, C, nullptr, 0, f1w, f1b, nullptr, big, M, 8 * C, 4 * C, EPI_GEGLU));
+            CK(linear(big, 4 * C, nullptr, 0, f2w, f2b, hb, hb, M, C, C));
+        }
         }   // transformer blocks
         WGET(pow_, p + "proj_out.weight"); WGET(pob, p + "proj_out.bias");
         CK(linear(hb, C, nullptr, 0, pow_, pob, xres, out->p, M, C, C));
@@ -524,6 +543,23 @@ int dsim_unet_finalize(dsim_unet* h, void* stream) {
             h->pk[p + suffix] = P;
         }
     }
+    // fused feed-forward (rowres.hip): one weight stream per transformer block of a width the kernel covers (bf16 only)
+    if (h->dt == DSIM_BF16) {
+        std::vector<std::string> ffs;
+        for (auto& kv : h->pk)
+            if (ends_with(kv.first, "ff.net.0.proj.weight") && ff_stream_bytes(kv.second.cols)) ffs.push_back(kv.first);
+        for (auto& k : ffs) {
+            const std::string b = k.substr(0, k.size() - strlen("ff.net.0.proj.weight"));
+            const Packed* w2 = h->find(b + "ff.net.2.weight");
+            if (!w2) return DSIM_ERR_MISSING_WEIGHT;
+            const int C = h->pk[k].cols;
+            Packed P;
+            P.rows = 1; P.cols = C; P.bytes = ff_stream_bytes(C);
+            CK(h->dalloc(P.bytes, &P.p));
+            CK(pack_ff_stream(h->pk[k].p, w2->p, P.p, C, s));
+            h->pk[b + "ff.stream"] = P;
+        }
+    }
     DSIM_HIP_CHECK(hipStreamSynchronize(s));
     h->raw.clear();
     h->finalized = true;
@@ -638,6 +674,12 @@ int dsim_unet_set_tap(dsim_unet* h, int tap_block, int tap_layer, int tap_attn, 
 int dsim_unet_set_cfg_dedup(dsim_unet* h, int enable) {
     if (!h) return DSIM_ERR_INVALID;
     h->cfg_dedup = enable != 0;
+    return DSIM_OK;
+}
+
+int dsim_unet_set_fusion(dsim_unet* h, int mask) {
+    if (!h || (mask & ~DSIM_FUSE_ALL)) return DSIM_ERR_INVALID;
+    h->fusion = mask;
     return DSIM_OK;
 }
 
@@ -800,6 +842,28 @@ int dsim_op_layernorm(const void* x, const float* gamma, const float* beta, void
                       void* stream) {
     hipStream_t s = (hipStream_t)stream;
     CK(launch_layernorm(x, gamma, beta, out, M, C, eps, dtype, s));
+    DSIM_HIP_CHECK(hipStreamSynchronize(s));
+    return DSIM_OK;
+}
+
+int dsim_op_ff_fused(const void* x, const float* ln_gamma, const float* ln_beta, const float* w1, const float* b1,
+                     const float* w2, const float* b2, void* out, int M, int C, float eps, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const size_t sb = ff_stream_bytes(C);
+    if (!sb || !x || !out || !w1 || !b1 || !w2 || !b2 || !ln_gamma || !ln_beta) return DSIM_ERR_INVALID;
+    Tmp t;
+    void* w1p = t.get((size_t)8 * C * C * 2);
+    float* b1p = (float*)t.get((size_t)8 * C * 4);
+    void* w2p = t.get((size_t)4 * C * C * 2);
+    void* st = t.get(sb);
+    if (!w1p || !b1p || !w2p || !st) return DSIM_ERR_HIP;
+    CK(pack_linear(w1, DSIM_F32, w1p, DSIM_BF16, 8 * C, C, 1, s));
+    CK(pack_vector(b1, DSIM_F32, b1p, 8 * C, 1, s));
+    CK(pack_linear(w2, DSIM_F32, w2p, DSIM_BF16, C, 4 * C, 0, s));
+    CK(pack_ff_stream(w1p, w2p, st, C, s));
+    FFArgs a;
+    a.x = x; a.out = out; a.ln_g = ln_gamma; a.ln_b = ln_beta; a.stream = st; a.b1 = b1p; a.b2 = b2; a.M = M; a.C = C; a.eps = eps;
+    CK(launch_ff_fused(a, s));
     DSIM_HIP_CHECK(hipStreamSynchronize(s));
     return DSIM_OK;
 }

@@ -55,7 +55,8 @@ class DiffSim:
     def __init__(self, torch_dtype=torch.bfloat16, device="cuda", ip_adapter=False, *,
                  unet_config: UNetConfig = SD15, state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  vae=None, encode_prompt: Optional[Callable[[str], torch.Tensor]] = None,
-                 vae_dtype=torch.float16, use_graphs: bool = False, noise_dtype=torch.float32, dedup_cfg: bool = False):
+                 vae_dtype=torch.float16, use_graphs: bool = False, noise_dtype=torch.float32, dedup_cfg: bool = False,
+                 fusion: Optional[int] = None):
         if ip_adapter:
             raise NotImplementedError("IP-Adapter mode is out of scope (SURVEY.md section 2 row 3)")
         if state_dict is None:
@@ -84,6 +85,7 @@ class DiffSim:
         # opt-in: conv_in, the first resnet and the first transformer's self-attention are identical in the two CFG halves
         # (torch.cat([latents] * 2), diffsim_pipeline.py:208); compute them once per image.  Bit-identical scores, ~6 % faster.
         self.dedup_cfg = bool(dedup_cfg)
+        self.fusion = fusion                    # None = the library default (every fused kernel); 0 = one launch per layer
         self._base: Optional[UNetEngine] = None
         self._engines: Dict[Tuple[str, int], object] = {}
         self._ctx: Dict[str, torch.Tensor] = {}
@@ -102,6 +104,8 @@ class DiffSim:
                 self._base.use_graphs = self.use_graphs
                 if self.dedup_cfg:
                     self._base.set_cfg_dedup(True)
+                if self.fusion is not None:
+                    self._base.set_fusion(self.fusion)
             self._engines[key] = self._base.view(target_block, int(target_layer))
             self._engines[key].tokens            # moves the tap once: a missing weight raises here, not mid-run
         return self._engines[key]

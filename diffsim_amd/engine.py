@@ -150,6 +150,13 @@ class UNetEngine:
         self._max_images = None
         self._graphs.clear()
 
+    def set_fusion(self, mask: int):
+        """Which multi-operator kernels replace their unfused chains (_lib.FUSE_* bits; default all).  0 = every layer
+        its own launch: the A/B switch of bench.py --fusion and of the parity tests."""
+        _lib.check(self.L.dsim_unet_set_fusion(self._h, int(mask)), "dsim_unet_set_fusion")
+        self._max_images = None
+        self._graphs.clear()
+
     def view(self, target_block: str, target_layer) -> "TapView":
         return TapView(self, target_block, target_layer)
 
@@ -347,6 +354,17 @@ def op_linear(x, w, bias=None, residual=None, geglu=False):
     out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     _lib.check(L.dsim_op_linear(x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), M, N, K,
                                 _TORCH2DSIM[x.dtype], int(geglu), _stream_ptr()), "op_linear")
+    return out
+
+
+def op_ff_fused(x, ln_g, ln_b, w1, b1, w2, b2, eps=1e-5):
+    """x + ff.net.2(GEGLU(ff.net.0.proj(LayerNorm(x)))) in one launch (bf16, C = 320); w1 [8C][C], w2 [C][4C] f32."""
+    L = _lib.lib()
+    _require_cuda(x, ln_g, ln_b, w1, b1, w2, b2)
+    M, Cc = x.shape
+    out = torch.empty_like(x)
+    _lib.check(L.dsim_op_ff_fused(x.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                  b2.data_ptr(), out.data_ptr(), M, Cc, float(eps), _stream_ptr()), "op_ff_fused")
     return out
 
 

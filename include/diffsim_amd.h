@@ -149,6 +149,13 @@ int  dsim_unet_set_tap(dsim_unet* h, int tap_block, int tap_layer, int tap_attn,
  * cross-attention query see two bit-identical halves (one time embedding: SD1.5 graphs only; ignored for SDXL and when the tap
  * lies in the first down block).  Scores are bit-identical to the default; 6 % fewer FLOPs are executed. */
 int  dsim_unet_set_cfg_dedup(dsim_unet* h, int enable);
+/* Which multi-operator kernels replace their unfused chains (bf16 handles; default DSIM_FUSE_ALL).  0 runs every layer as its own
+ * launch -- the A/B switch of bench.py --fusion and of the parity tests; results agree to bf16 rounding, not bit for bit.
+ * DSIM_FUSE_FF: norm3 -> ff.net.0.proj (GEGLU) -> ff.net.2 -> + residual of a 320-channel BasicTransformerBlock as one launch
+ * (hacked_modules.py:118-132). */
+#define DSIM_FUSE_FF  1
+#define DSIM_FUSE_ALL 1
+int  dsim_unet_set_fusion(dsim_unet* h, int mask);
 /* Latent side of the next dsim_unet_qkv calls (cfg.sample_size is only the default): the reference runs any
  * --image_size through the same weights (argprocess.py:8: default 512 px, SDXL native 1024 px).  `side` must be a
  * multiple of 2^(n_levels-1). */
@@ -263,6 +270,13 @@ int dsim_op_attention(const void* q, int ldq, const void* k, const void* v, int 
 /* the same attention on bf16 tensors with fp8 (e4m3) MFMAs -- the kernel behind dsim_dit_set_attention(h, 1); D = 72 or 32 */
 int dsim_op_attention_fp8(const void* q, int ldq, const void* k, const void* v, int ldk, void* out,
                           int ldo, int B, int Bkv, int H, int Nq, int Nk, int D, void* stream);
+
+/* One BasicTransformerBlock feed-forward as a single launch (bf16, C = 320): out = x + ff.net.2(GEGLU(ff.net.0.proj(LayerNorm(x))))
+ * -- the chain /root/reference/diffsim/hacked_modules.py:118-132 runs as norm3 -> ff -> + hidden_states.  w1: [8C][C] f32 (diffusers
+ * ff.net.0.proj.weight, rows [h ; g]), b1: [8C], w2: [C][4C], b2: [C]; x / out: bf16 [M][C] (out may alias x).
+ * Returns DSIM_ERR_INVALID for a width the fused kernel does not cover.                                                   */
+int dsim_op_ff_fused(const void* x, const float* ln_gamma, const float* ln_beta, const float* w1, const float* b1,
+                     const float* w2, const float* b2, void* out, int M, int C, float eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -373,3 +373,39 @@ def test_attention_peaked_logits(eng, dtype, D, scale):
     got = eng.op_attention(_dev(q, dtype), _dev(k, dtype), _dev(v, dtype), H)
     assert torch.isfinite(got.float()).all()
     _close(got, want, dtype)
+
+
+@pytest.mark.parametrize("M", [128, 96, 4096 + 32, 40000])
+def test_ff_fused_320(eng, M):
+    """LayerNorm -> GEGLU projection -> ff.net.2 -> + residual as ONE launch (row-resident kernel, bf16, C = 320) against
+    the fp32 CPU chain (hacked_modules.py:118-132) and against the three-launch HIP chain it replaces."""
+    C = 320
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, C, generator=g) * 1.5 + 0.3
+    lg, lb = torch.randn(C, generator=g) * 0.2 + 1.0, torch.randn(C, generator=g) * 0.1
+    w1 = torch.randn(8 * C, C, generator=g) / math.sqrt(C)
+    b1 = torch.randn(8 * C, generator=g) * 0.5
+    w2 = torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C)
+    b2 = torch.randn(C, generator=g) * 0.5
+    xq = _q(x, dtype)
+    n = _q(F.layer_norm(xq, (C,), lg, lb, 1e-5), dtype)
+    hh, gg = F.linear(n, _q(w1, dtype), b1).chunk(2, dim=-1)
+    hid = _q(hh * F.gelu(gg), dtype)
+    want = xq + F.linear(hid, _q(w2, dtype), b2)
+    xd = _dev(x, dtype)
+    got = eng.op_ff_fused(xd, _dev(lg), _dev(lb), _dev(w1), _dev(b1), _dev(w2), _dev(b2))
+    _close(got, want, dtype)
+    # the unfused HIP chain on the same inputs: same roundings at the same places, so the two agree much tighter than the gate
+    n_h = eng.op_layernorm(xd, _dev(lg), _dev(lb), 1e-5)
+    hid_h = eng.op_linear(n_h, _dev(w1), _dev(b1), None, geglu=True)
+    ref_h = eng.op_linear(hid_h, _dev(w2), _dev(b2), xd)
+    d = (got.float() - ref_h.float()).abs().max().item()
+    assert d <= float(want.abs().max()) / 64, d       # two bf16 ulps of the largest output
+    # in place (out aliases x), as the U-Net executor calls it; and bit-reproducible
+    L = eng._lib.lib()
+    x2 = xd.clone()
+    ws = [_dev(t) for t in (lg, lb, w1, b1, w2, b2)]
+    eng._lib.check(L.dsim_op_ff_fused(x2.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ws[3].data_ptr(),
+                                      ws[4].data_ptr(), ws[5].data_ptr(), x2.data_ptr(), M, C, 1e-5, None), "ff in place")
+    assert torch.equal(x2, got)

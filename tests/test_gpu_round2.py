@@ -255,3 +255,38 @@ def test_cfg_dedup_is_bit_identical():
     a = xl.score_latent_pairs(za, zb, n[2], n[3], xctx, pooled, "up_blocks", [0, 1, 2], 600)
     xl.engine("up_blocks", [0, 1, 2]).set_cfg_dedup(True)
     assert torch.equal(a, xl.score_latent_pairs(za, zb, n[2], n[3], xctx, pooled, "up_blocks", [0, 1, 2], 600))
+
+
+def test_fused_kernels_agree_with_their_unfused_chains():
+    """dsim_unet_set_fusion: the row-resident feed-forward launch (norm3 -> GEGLU projection -> ff.net.2 -> + residual of
+    the 320-channel blocks) against the three launches it replaces, on the SD1.5 channel plan: the q/k/v of a tap behind
+    both 320-channel transformer blocks and the scores agree to bf16 rounding (same rounding points, other summation
+    order); the switch is a no-op in fp32 mode (no fused kernel there) and the workspace plan follows the mask."""
+    from diffsim_amd import _lib
+    cfg = C.UNetConfig(sample_size=16)
+    keys = [k for k in C.unet_param_shapes(cfg) if not k.startswith(("up_blocks.2", "up_blocks.3", "conv_norm_out", "conv_out"))]
+    sd = S.make_state_dict(cfg, seed=0, keys=keys)
+    ctx = S.make_context(cfg)
+    lat = [S.make_pair_latents(cfg, i) for i in range(3)]
+    zA, zB = torch.cat([p[0] for p in lat]), torch.cat([p[1] for p in lat])
+    n = S.draw_pair_noise(2334, lat[0][0].shape)
+    fused, plain = _ds(cfg, sd, torch.bfloat16), _ds(cfg, sd, torch.bfloat16, fusion=0)
+    for blk, layer in (("down_blocks", 1), ("up_blocks", 0)):
+        a = fused.score_latent_pairs(zA, zB, n[2], n[3], ctx, blk, layer, 600, "cosine")
+        b = plain.score_latent_pairs(zA, zB, n[2], n[3], ctx, blk, layer, 600, "cosine")
+        assert (a - b).abs().max().item() <= 2e-3, (blk, layer, a, b)
+        assert torch.equal(a, fused.score_latent_pairs(zA, zB, n[2], n[3], ctx, blk, layer, 600, "cosine"))    # reproducible
+    ef, ep = fused.engine("down_blocks", 1), plain.engine("down_blocks", 1)
+    ef.profile(True); ep.profile(True)
+    fused.score_latent_pairs(zA[:1], zB[:1], n[2], n[3], ctx, "down_blocks", 1, 600, "cosine")
+    plain.score_latent_pairs(zA[:1], zB[:1], n[2], n[3], ctx, "down_blocks", 1, 600, "cosine")
+    ff = [r[0] for r in ef.profile_records()]
+    fp = [r[0] for r in ep.profile_records()]
+    ef.profile(False); ep.profile(False)
+    assert ff.count("ff_fused_bf16") == 2 and "ff_fused_bf16" not in fp
+    assert len(fp) - len(ff) == 4              # two blocks x (LayerNorm + GEGLU GEMM + ff.net.2 -> one launch)
+    with pytest.raises(_lib.DsimError):
+        ef.set_fusion(8)
+    f32a, f32b = _ds(cfg, sd, torch.float32), _ds(cfg, sd, torch.float32, fusion=0)
+    assert torch.equal(f32a.score_latent_pairs(zA[:1], zB[:1], n[2], n[3], ctx, "down_blocks", 1, 600, "cosine"),
+                       f32b.score_latent_pairs(zA[:1], zB[:1], n[2], n[3], ctx, "down_blocks", 1, 600, "cosine"))

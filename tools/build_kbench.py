@@ -1,17 +1,29 @@
-"""Build tools/kbench (kernel micro-benchmark; development aid) against the library's object files."""
+"""Build tools/kbench (kernel micro-benchmark; development aid): the library's sources compiled with -DDSIM_DEVTOOLS
+(tile overrides, environment switches, ablation instantiations -- none of which exist in the product library)."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from diffsim_amd import build as B  # noqa: E402
 
-B.build()
-objs = [os.path.join(B.OBJ, s.replace(".hip", ".o")) for s in B.SOURCES]
+OBJ = os.path.join(B.CSRC, "_obj_dev")
+os.makedirs(OBJ, exist_ok=True)
+
+
+def cc(src):
+    path = os.path.join(ROOT, "tools", src) if src == "kbench.hip" else os.path.join(B.CSRC, src)
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    if B._stale(obj, [path] + B.HEADERS):
+        subprocess.run([B.HIPCC] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + ["-DDSIM_DEVTOOLS", "-c", path, "-o", obj], check=True)
+    return obj
+
+
+only = [s for s in B.SOURCES if s not in ("unet.hip", "vae.hip", "dit.hip")]        # kbench calls the kernels directly
+with ThreadPoolExecutor(max_workers=4) as ex:
+    objs = list(ex.map(cc, only + ["kbench.hip"]))
 out = os.path.join(ROOT, "tools", "kbench")
-ko = os.path.join(B.OBJ, "kbench.o")
-subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", os.path.join(ROOT, "tools", "kbench.hip"), "-o", ko],
-               check=True)
-subprocess.run([B.HIPCC, "--offload-arch=gfx950", ko] + objs + ["-o", out], check=True)
+subprocess.run([B.HIPCC, "--offload-arch=gfx950"] + objs + ["-o", out], check=True)
 print("built", out)

@@ -135,6 +135,55 @@ static void bench_gn(const char* name, int B, int HW, int C, int iters, Timer& t
     HC(hipFree(x)); HC(hipFree(g)); HC(hipFree(b)); HC(hipFree(out)); HC(hipFree(sc));
 }
 
+// fused feed-forward (rowres.hip) against the three launches it replaces: LayerNorm, GEGLU projection, ff.net.2 + residual
+static void bench_ff(const char* name, int M, int iters, Timer& t, void* zp) {
+    if (!want(name)) return;
+    const int C = 320;
+    void* x = dalloc_bf16((size_t)M * C, 1);
+    void* w1 = dalloc_bf16((size_t)8 * C * C, 2, 0.05f);
+    void* w2 = dalloc_bf16((size_t)4 * C * C, 3, 0.03f);
+    float* b1 = dalloc_f32(8 * C, 4);
+    float* b2 = dalloc_f32(C, 5);
+    float* lg = dalloc_f32(C, 6);
+    float* lb = dalloc_f32(C, 7);
+    void *st, *nb, *big, *out;
+    HC(hipMalloc(&st, ff_stream_bytes(C)));
+    HC(hipMalloc(&nb, (size_t)M * C * 2));
+    HC(hipMalloc(&big, (size_t)M * 4 * C * 2));
+    HC(hipMalloc(&out, (size_t)M * C * 2));
+    int s0 = pack_ff_stream(w1, w2, st, C, 0);
+    FFArgs a;
+    a.x = x; a.out = out; a.ln_g = lg; a.ln_b = lb; a.stream = st; a.b1 = b1; a.b2 = b2; a.M = M; a.C = C;
+    int s1 = DSIM_OK;
+    const float msf = t.run([&] { s1 = launch_ff_fused(a, 0); }, iters);
+    if (const char* e = getenv("KB_FFDBG")) {           // ablation masks, e.g. KB_FFDBG=1,2,4,8,16
+        std::string l = e;
+        size_t pos = 0;
+        printf("  ff ablation (ms by mask): 0:%.3f", msf);
+        while (pos < l.size()) {
+            size_t nx = l.find(',', pos);
+            if (nx == std::string::npos) nx = l.size();
+            g_ff_dbg = atoi(l.substr(pos, nx - pos).c_str());
+            printf("  %d:%.3f", g_ff_dbg, t.run([&] { s1 |= launch_ff_fused(a, 0); }, iters));
+            pos = nx + 1;
+        }
+        g_ff_dbg = 0;
+        printf("\n");
+    }
+    GemmArgs g1, g2;
+    g1.A0 = nb; g1.C0 = C; g1.M = M; g1.N = 8 * C; g1.K = C; g1.W = w1; g1.bias = b1; g1.epi = EPI_GEGLU; g1.out = big; g1.ldo = 4 * C; g1.zero_page = zp;
+    g2.A0 = big; g2.C0 = 4 * C; g2.M = M; g2.N = C; g2.K = 4 * C; g2.W = w2; g2.bias = b2; g2.epi = EPI_RESIDUAL; g2.residual = x; g2.out = out; g2.ldo = C; g2.zero_page = zp;
+    g_force_bm = 0;
+    const float msl = t.run([&] { s1 |= launch_layernorm(x, lg, lb, nb, M, C, 1e-5f, DSIM_BF16, 0); }, iters);
+    const float ms1 = t.run([&] { s1 |= launch_gemm(g1, DSIM_BF16, 0); }, iters);
+    const float ms2 = t.run([&] { s1 |= launch_gemm(g2, DSIM_BF16, 0); }, iters);
+    const double fl = 2.0 * M * (double)C * 12 * C;
+    printf("%-26s M=%7d  fused %7.3f ms %6.1f TF | ln %6.3f + geglu %6.3f + net2 %6.3f = %7.3f ms %6.1f TF  st=%d/%d\n", name, M, msf,
+           fl / msf / 1e9, msl, ms1, ms2, msl + ms1 + ms2, fl / (msl + ms1 + ms2) / 1e9, s0, s1);
+    HC(hipFree(x)); HC(hipFree(w1)); HC(hipFree(w2)); HC(hipFree(b1)); HC(hipFree(b2)); HC(hipFree(lg)); HC(hipFree(lb));
+    HC(hipFree(st)); HC(hipFree(nb)); HC(hipFree(big)); HC(hipFree(out));
+}
+
 int main(int argc, char** argv) {
     const int B2 = argc > 1 ? atoi(argv[1]) : 64;
     const int iters = argc > 2 ? atoi(argv[2]) : 10;
@@ -144,6 +193,7 @@ int main(int argc, char** argv) {
     HC(hipMemset(zp, 0, 256));
     Timer t;
     const int s64 = B2 * 4096, s32 = B2 * 1024, s16 = B2 * 256, s8 = B2 * 64;
+    bench_ff("ff_64_320_fused", s64, iters, t, zp);
     // ---- 3x3 convs ----
     bench_gemm("conv3_64_320_320", GEMM_CONV3, s64, 320, 320, 64, 64, EPI_NONE, iters, t, zp);
     bench_gemm("conv3_64_320_320_res", GEMM_CONV3, s64, 320, 320, 64, 64, EPI_RESIDUAL, iters, t, zp);

@@ -69,6 +69,7 @@ extern int g_gn_onepass;        // DSIM_GN_ONEPASS
 extern int g_ln_rows;           // DSIM_LN_ROWS
 extern int g_prep8;             // DSIM_PREP8
 extern int g_ff_dbg;            // ablation mask of the fused feed-forward kernel (rowres.hip)
+extern int g_ff_stagger;        // its wave de-phasing, in s_nop 7 units per wave index
 #else
 constexpr int g_gemm_persistent = 1, g_force_bm = 0, g_gn_onepass = 1, g_ln_rows = 1, g_prep8 = 1;
 #endif

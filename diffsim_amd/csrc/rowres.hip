@@ -88,6 +88,7 @@ struct FFParams {
     int M;
     float eps;
     unsigned x_bytes, stream_bytes;
+    int stagger;            // s_nop 7 units (8 wait states each) wave w idles after every ring barrier, times w
 };
 
 // DBG (development builds only, tools/kbench ablations; the product instantiates DBG = 0): 1 no weight DMA, 2 no GELU,
@@ -208,6 +209,13 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FFParams p, cons
         bf16x8 q0, q1;            // ... of chunk it-1, being produced
         float hv[16];
 
+        // wave w idles w * stagger units after each ring barrier: the loop lives inside one asm statement, so hipcc's
+        // control-flow graph (and with it the pinned schedule and the register allocation) does not see a branch here
+        auto stagger_wait = [&]() {
+            int cnt = wave * p.stagger;
+            asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lstag_end_%=\n.Lstag_%=:\n\ts_nop 7\n\ts_sub_u32 %0, %0, 1\n\t"
+                         "s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 .Lstag_%=\n.Lstag_end_%=:" : "+s"(cnt) :: "scc");
+        };
         // accumulators of chunk c start at its b1 slice
         auto init1 = [&](int c, f32x16& h, f32x16& gg) {
 #pragma unroll
@@ -278,9 +286,10 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FFParams p, cons
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
 #define RR_BODY(PAR, C, G1, GL, G2, NEXT_CI)                                                                          \
         {                                                                                                             \
-            constexpr int NG = ((G1) ? 10 : 0) + ((G2) ? 5 : 0), NH = (NG + 1) / 2;                                   \
+            constexpr int NG = ((G1) ? 10 : 0) + ((G2) ? 5 : 0), NH = NG == 15 ? 12 : (NG == 10 ? 8 : 4);             \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                          \
             __syncthreads();                                                                                          \
+            stagger_wait();                        /* de-phase the four waves */                                      \
             const char* slot = smem + (PAR) * RCHB;                                                                   \
             if (G1) { init1((C), aH[PAR], aG[PAR]); ld1(slot, 0, wf[0]); } else ld2(slot, 0, wf[0]);                  \
             RR_SB;                                                                                                    \
@@ -354,6 +363,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FFParams p, cons
 
 #ifdef DSIM_DEVTOOLS
 int g_ff_dbg = 0;
+int g_ff_stagger = -1;     // -1 = the product default
 #endif
 
 size_t ff_stream_bytes(int C) { return C == RC ? (size_t)RITER * RCHB : 0; }
@@ -374,6 +384,13 @@ int launch_ff_fused(const FFArgs& a, hipStream_t s) {
     p.b1 = a.b1; p.b2 = a.b2; p.M = a.M; p.eps = a.eps;
     p.x_bytes = (unsigned)((size_t)a.M * RC * 2);
     p.stream_bytes = (unsigned)((size_t)RITER * RCHB);
+    // The four waves of a workgroup leave every ring barrier together and would issue their DMA pieces (and fragment reads) at
+    // the same instants: they then queue on the CU's one vector-memory path (~16-23 cycles per 1 KB piece) and each piece costs
+    // its wave ~80 cycles of issue stall.  De-phased by 3 x 8 wait states per wave index: 1.48 -> 1.24 ms (sweep in profiles/).
+    p.stagger = 3;
+#ifdef DSIM_DEVTOOLS
+    if (g_ff_stagger >= 0) p.stagger = g_ff_stagger;
+#endif
     const int ntiles = (a.M + 127) / 128;
     const int grid = ntiles < cu_count() ? ntiles : cu_count();
 #ifdef DSIM_DEVTOOLS

@@ -156,6 +156,20 @@ static void bench_ff(const char* name, int M, int iters, Timer& t, void* zp) {
     a.x = x; a.out = out; a.ln_g = lg; a.ln_b = lb; a.stream = st; a.b1 = b1; a.b2 = b2; a.M = M; a.C = C;
     int s1 = DSIM_OK;
     const float msf = t.run([&] { s1 = launch_ff_fused(a, 0); }, iters);
+    if (const char* e = getenv("KB_FFSTAG")) {          // wave de-phasing sweep, e.g. KB_FFSTAG=1,2,4,8
+        std::string l = e;
+        size_t pos = 0;
+        printf("  ff stagger (ms): default:%.3f", msf);
+        while (pos < l.size()) {
+            size_t nx = l.find(',', pos);
+            if (nx == std::string::npos) nx = l.size();
+            g_ff_stagger = atoi(l.substr(pos, nx - pos).c_str());
+            printf("  %d:%.3f", g_ff_stagger, t.run([&] { s1 |= launch_ff_fused(a, 0); }, iters));
+            pos = nx + 1;
+        }
+        g_ff_stagger = -1;
+        printf("\n");
+    }
     if (const char* e = getenv("KB_FFDBG")) {           // ablation masks, e.g. KB_FFDBG=1,2,4,8,16
         std::string l = e;
         size_t pos = 0;

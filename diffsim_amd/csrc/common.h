@@ -58,6 +58,9 @@ struct GemmArgs {
     int ldo = 0;
     const void* zero_page = nullptr;            // >= 16 zero bytes (kept for ABI stability; padding now comes from OOB buffer reads)
     unsigned a0_bytes = 0, a1_bytes = 0, w_bytes = 0, out_bytes = 0;   // filled by launch_gemm: operand extents for the buffer descriptors
+#ifdef DSIM_DEVTOOLS
+    int exp = 0;                                // kernel experiments (tools/kbench)
+#endif
 };
 int launch_gemm(const GemmArgs& a, int dtype, hipStream_t s);
 // Development switches (kernel A/B in tools/kbench, environment overrides): they exist only in -DDSIM_DEVTOOLS builds
@@ -65,6 +68,7 @@ int launch_gemm(const GemmArgs& a, int dtype, hipStream_t s);
 #ifdef DSIM_DEVTOOLS
 extern int g_gemm_persistent;   // 0 = one tile per workgroup
 extern int g_force_bm;          // 0 = heuristic; 128/256 force the row tile
+extern int g_gemm_exp;          // experiment mask passed to gemm_kernel
 extern int g_gn_onepass;        // DSIM_GN_ONEPASS
 extern int g_ln_rows;           // DSIM_LN_ROWS
 extern int g_prep8;             // DSIM_PREP8

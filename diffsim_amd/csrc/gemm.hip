@@ -25,6 +25,7 @@ namespace dsim {
 #ifdef DSIM_DEVTOOLS
 int g_force_bm = 0;
 int g_gemm_persistent = 1;
+int g_gemm_exp = 0;
 #endif
 // Tile choice.  Small problems: 128-row tiles, 4 waves, two workgroups per CU (160-wide when N
 // allows -- every SD channel count is a multiple of 160 -- else 128).  bf16 problems with enough
@@ -374,7 +375,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
         load_set(b0, 0, 0);
         for (int t = 0; t < nk; ++t) {
             const int cur = b0 ^ (t & 1);
+#ifdef DSIM_EXP_LATE
+            const bool late = wave_u >= NW / 2;      // experiment: the upper half of the waves stages one sub-step later
+            if (t + 1 < nk && !late) stage(t + 1, cur ^ 1);
+#else
             if (t + 1 < nk) stage(t + 1, cur ^ 1);
+#endif
 #pragma unroll
             for (int kk = 0; kk + 1 < KSUB; ++kk) {
                 load_set(cur, kk + 1, (kk + 1) & 1);
@@ -383,9 +389,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                 __builtin_amdgcn_sched_barrier(0);
                 mma_set(kk & 1);
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef DSIM_EXP_LATE
+                if (kk == 0 && t + 1 < nk && late) stage(t + 1, cur ^ 1);
+#endif
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                    // (also drains this wave's fragment reads of `cur`)
+#ifdef DSIM_DEVTOOLS
+            {   // experiment: de-phase the waves after the K-tile barrier (units of s_nop 7: bits 0-3 per wave index, bits 5-8 upper half only)
+                int cnt = wave_u * (p.exp & 15) + (wave_u >= NW / 2 ? ((p.exp >> 5) & 15) : 0);
+                asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lgst_end_%=\n.Lgst_%=:\n\ts_nop 7\n\ts_sub_u32 %0, %0, 1\n\t"
+                             "s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc1 .Lgst_%=\n.Lgst_end_%=:" : "+s"(cnt) :: "scc");
+            }
+#endif
             if (t + 1 < nk) load_set(cur ^ 1, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             mma_set((KSUB - 1) & 1);                            // the tile's last sub-step, from registers
@@ -591,6 +607,9 @@ int launch_ek(const GemmArgs& a, hipStream_t s) {
     const size_t ob = (size_t)a.M * a.ldo * es;        // output (and residual) extent: rows are ldo elements apart
     if (a0b >= 0x7fffffffull || a1b >= 0x7fffffffull || wb >= 0x7fffffffull || ob >= 0x7fffffffull) return DSIM_ERR_INVALID;
     g.a0_bytes = (unsigned)a0b; g.a1_bytes = (unsigned)a1b; g.w_bytes = (unsigned)wb; g.out_bytes = (unsigned)ob;
+#ifdef DSIM_DEVTOOLS
+    g.exp = g_gemm_exp;
+#endif
     // persistent grid: as many workgroups as stay resident (LDS-limited), a multiple of 8 so a workgroup keeps its XCD
     const int ntiles = tilesM * tilesN;
     const int resident = ((cu_count() * (LDS <= 80 * 1024 ? 2 : 1)) / 8) * 8;

@@ -384,10 +384,10 @@ int launch_ff_fused(const FFArgs& a, hipStream_t s) {
     p.b1 = a.b1; p.b2 = a.b2; p.M = a.M; p.eps = a.eps;
     p.x_bytes = (unsigned)((size_t)a.M * RC * 2);
     p.stream_bytes = (unsigned)((size_t)RITER * RCHB);
-    // The four waves of a workgroup leave every ring barrier together and would issue their DMA pieces (and fragment reads) at
-    // the same instants: they then queue on the CU's one vector-memory path (~16-23 cycles per 1 KB piece) and each piece costs
-    // its wave ~80 cycles of issue stall.  De-phased by 3 x 8 wait states per wave index: 1.48 -> 1.24 ms (sweep in profiles/).
-    p.stagger = 3;
+    // The four waves of a workgroup leave every ring barrier together and issue their DMA pieces and fragment reads at the same
+    // instants; de-phased by one 8-wait-state unit per wave index the kernel runs 1.7 % faster (interleaved-round sweep in
+    // profiles/r03_ff_fused_ablation.txt: 0 -> 1.208, 1 -> 1.187, 2 -> 1.218, 3 -> 1.246 ms).
+    p.stagger = 1;
 #ifdef DSIM_DEVTOOLS
     if (g_ff_stagger >= 0) p.stagger = g_ff_stagger;
 #endif

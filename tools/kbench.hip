@@ -2,6 +2,7 @@
 // attention / norm kernels on the exact shapes of one SD1.5 step (B2 U-Net batch elements) with HIP
 // events, random bf16 data.  Build: python tools/build_kbench.py ; run on the GPU box:
 //   ./tools/kbench [B2=64] [iters=10] [filter]
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -87,6 +88,31 @@ static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H,
         if (v == 0 && getenv("KB_NOPERSIST")) { g_force_bm = 0; g_gemm_persistent = 0; }   // column 1 = auto tiles, one tile per workgroup
         msv[v] = t.run([&] { st = launch_gemm(g, DSIM_BF16, 0); }, iters);
     }
+    if (const char* e = getenv("KB_GEXP")) {            // kernel experiment masks on the auto tile, e.g. KB_GEXP=32,64,128
+        // interleaved rounds in one process (cdna_hip_programming.md rule 24): every mask (0 first) timed once per round, min and median
+        std::vector<int> masks{0};
+        std::string l = e;
+        for (size_t pos = 0; pos < l.size();) {
+            size_t nx = l.find(',', pos);
+            if (nx == std::string::npos) nx = l.size();
+            masks.push_back(atoi(l.substr(pos, nx - pos).c_str()));
+            pos = nx + 1;
+        }
+        const int rounds = getenv("KB_ROUNDS") ? atoi(getenv("KB_ROUNDS")) : 5;
+        std::vector<std::vector<float>> ms(masks.size());
+        for (int r = 0; r < rounds; ++r)
+            for (size_t k = 0; k < masks.size(); ++k) {
+                g_gemm_exp = masks[k];
+                ms[k].push_back(t.run([&] { st = launch_gemm(g, DSIM_BF16, 0); }, iters));
+            }
+        g_gemm_exp = 0;
+        printf("  gemm exp min/median ms:");
+        for (size_t k = 0; k < masks.size(); ++k) {
+            std::sort(ms[k].begin(), ms[k].end());
+            printf("  %d:%.3f/%.3f", masks[k], ms[k][0], ms[k][rounds / 2]);
+        }
+        printf("\n");
+    }
     int bm, bn;
     gemm_tile_choice(g, &bm, &bn);
     printf("%-26s M=%7d N=%5d K=%5d  bm128 %7.3f ms %6.1f TF | bm256 %7.3f ms %6.1f TF | auto %dx%d %7.3f ms %6.1f TF st=%d\n",
@@ -156,34 +182,35 @@ static void bench_ff(const char* name, int M, int iters, Timer& t, void* zp) {
     a.x = x; a.out = out; a.ln_g = lg; a.ln_b = lb; a.stream = st; a.b1 = b1; a.b2 = b2; a.M = M; a.C = C;
     int s1 = DSIM_OK;
     const float msf = t.run([&] { s1 = launch_ff_fused(a, 0); }, iters);
-    if (const char* e = getenv("KB_FFSTAG")) {          // wave de-phasing sweep, e.g. KB_FFSTAG=1,2,4,8
+    // interleaved rounds (rule 24): KB_FFSTAG=0,1,2,3,4 sweeps the wave de-phasing, KB_FFDBG=1,2,3 the ablation masks
+    auto sweep = [&](const char* env, const char* label, int* knob, int restore) {
+        const char* e = getenv(env);
+        if (!e) return;
+        std::vector<int> vals;
         std::string l = e;
-        size_t pos = 0;
-        printf("  ff stagger (ms): default:%.3f", msf);
-        while (pos < l.size()) {
+        for (size_t pos = 0; pos < l.size();) {
             size_t nx = l.find(',', pos);
             if (nx == std::string::npos) nx = l.size();
-            g_ff_stagger = atoi(l.substr(pos, nx - pos).c_str());
-            printf("  %d:%.3f", g_ff_stagger, t.run([&] { s1 |= launch_ff_fused(a, 0); }, iters));
+            vals.push_back(atoi(l.substr(pos, nx - pos).c_str()));
             pos = nx + 1;
         }
-        g_ff_stagger = -1;
-        printf("\n");
-    }
-    if (const char* e = getenv("KB_FFDBG")) {           // ablation masks, e.g. KB_FFDBG=1,2,4,8,16
-        std::string l = e;
-        size_t pos = 0;
-        printf("  ff ablation (ms by mask): 0:%.3f", msf);
-        while (pos < l.size()) {
-            size_t nx = l.find(',', pos);
-            if (nx == std::string::npos) nx = l.size();
-            g_ff_dbg = atoi(l.substr(pos, nx - pos).c_str());
-            printf("  %d:%.3f", g_ff_dbg, t.run([&] { s1 |= launch_ff_fused(a, 0); }, iters));
-            pos = nx + 1;
+        const int rounds = getenv("KB_ROUNDS") ? atoi(getenv("KB_ROUNDS")) : 5;
+        std::vector<std::vector<float>> ms(vals.size());
+        for (int r = 0; r < rounds; ++r)
+            for (size_t k = 0; k < vals.size(); ++k) {
+                *knob = vals[k];
+                ms[k].push_back(t.run([&] { s1 |= launch_ff_fused(a, 0); }, iters));
+            }
+        *knob = restore;
+        printf("  ff %s min/median ms:", label);
+        for (size_t k = 0; k < vals.size(); ++k) {
+            std::sort(ms[k].begin(), ms[k].end());
+            printf("  %d:%.3f/%.3f", vals[k], ms[k][0], ms[k][rounds / 2]);
         }
-        g_ff_dbg = 0;
         printf("\n");
-    }
+    };
+    sweep("KB_FFSTAG", "stagger", &g_ff_stagger, -1);
+    sweep("KB_FFDBG", "ablation", &g_ff_dbg, 0);
     GemmArgs g1, g2;
     g1.A0 = nb; g1.C0 = C; g1.M = M; g1.N = 8 * C; g1.K = C; g1.W = w1; g1.bias = b1; g1.epi = EPI_GEGLU; g1.out = big; g1.ldo = 4 * C; g1.zero_page = zp;
     g2.A0 = big; g2.C0 = 4 * C; g2.M = M; g2.N = C; g2.K = 4 * C; g2.W = w2; g2.bias = b2; g2.epi = EPI_RESIDUAL; g2.residual = x; g2.out = out; g2.ldo = C; g2.zero_page = zp;

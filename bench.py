@@ -425,7 +425,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch-pairs", type=int, default=32, help="pairs per sub-batch (one U-Net batch = 4 x this many elements)")
+    ap.add_argument("--batch-pairs", type=int, default=None,
+                    help="pairs per sub-batch (one U-Net batch = 4 x this many elements); 64 = the largest whose activations stay < 2 GiB")
     ap.add_argument("--streams", type=int, default=1,
                     help="concurrent sub-batches per step, one HIP stream each (a step then scores streams x batch-pairs pairs).  "
                          "2 is ~2 %% faster (one sub-batch's norm kernels run under the other's GEMMs) and is what "
@@ -453,13 +454,15 @@ def main():
     ap.add_argument("--selftest-launch", action="store_true",
                     help="CPU-only check of the N-rank launch + gloo plumbing (no kernels, no throughput)")
     a = ap.parse_args()
+    if a.batch_pairs is None:
+        a.batch_pairs = {"sd15": 16 if a.pixels_in else 64, "sdxl": 8, "dit": 64}[a.model]
 
     # ---- N ranks: either a torch.distributed launcher started us (WORLD_SIZE set), or we start them ourselves -----
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        if not a.selftest_launch and torch.cuda.device_count() < a.gpus:      # device_count() does not initialise HIP
-            raise SystemExit(f"bench.py: --gpus {a.gpus} but only {torch.cuda.device_count()} GPU(s) visible")
+        # the parent never touches the HIP runtime (not even to count devices): a rank that has no GPU says so itself
+        # ("rank r needs GPU k, only n visible") and the supervisor stops the others
         raise SystemExit(launch_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

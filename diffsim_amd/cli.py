@@ -171,6 +171,9 @@ def run(args) -> int:
 def main(argv=None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
     args = arg_parse(argv)
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.ngpu:
+        raise SystemExit(f"--ngpu {args.ngpu} but WORLD_SIZE={os.environ['WORLD_SIZE']}: refusing to run a mislabelled launch "
+                         f"(pass --ngpu equal to the number of ranks the launcher started)")
     if args.ngpu > 1 and "WORLD_SIZE" not in os.environ:
         from .parallel import spawn_ranks              # the parent never touches the GPU
         return spawn_ranks(args.ngpu, [sys.executable, "-m", "diffsim_amd"] + argv)

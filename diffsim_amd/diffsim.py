@@ -173,15 +173,16 @@ class DiffSim:
         """Batched latents-in scoring: pair i = (latA[i], latB[i]) -> scores (n,) f32 on device.
         noiseA/noiseB are (1,4,s,s) (shared by every pair: each reference call reseeds) or (n,4,s,s).
         Consecutive chunks of `batch_pairs` pairs are enqueued on `streams` HIP streams in turn, so the HBM-bound kernels of
-        one chunk overlap the MFMA-bound kernels of the next (same kernels, same scores)."""
+        one chunk overlap the MFMA-bound kernels of the next (same kernels, same scores).  Each stream in use owns one
+        workspace arena of the engine (streams = 2 -> two arenas, ~0.75 GB per pair of the chunk size each)."""
         n = latA.shape[0]
         eng = self.engine(target_block, target_layer)
         out = torch.empty(n, dtype=torch.float32, device=self.device)
         batch_pairs = max(1, min(batch_pairs, eng.max_images() // 2))      # every activation must stay < 2 GiB
         starts = list(range(0, n, batch_pairs))
         ns = max(1, min(int(streams), len(starts)))
-        if self.use_graphs:
-            ns = 1
+        if self.use_graphs or getattr(eng, "_profiling", False):
+            ns = 1          # (per-launch profile brackets are only a kernel's own time when nothing overlaps it)
         main = torch.cuda.current_stream(self.device)
         if ns > 1:
             if len(self._streams) < ns:

@@ -133,16 +133,20 @@ class UNetEngine:
         tl, ta, tt = resolve_tap(self.cfg, target_block, target_layer)
         _lib.check(self.L.dsim_unet_set_tap(self._h, _lib.TAP[target_block], tl, ta, tt), "dsim_unet_set_tap")
         self.target_block, self.target_layer = target_block, target_layer
-        self._refresh_tap_shape()
-        self._graphs.clear()
+        self._refresh_tap_shape()           # (captured hipGraphs are keyed by tap and latent side: a sweep that alternates
+                                            #  between taps keeps both graphs instead of re-capturing at every switch)
 
     def set_sample_size(self, side: int):
         """Latent side of the next qkv() calls (cfg.sample_size is the default, not a limit)."""
         if side != self.sample_size:
+            m = 1 << (len(self.cfg.block_out_channels) - 1)
+            if side < m or side % m:
+                raise ValueError(f"latent side {side} (--image_size {8 * side}) must be a multiple of {m}, i.e. --image_size a "
+                                 f"multiple of {8 * m}: this engine has no ragged down/up-sampling path (diffusers' "
+                                 f"forward_upsample_size), so e.g. 224 px is refused rather than silently resized")
             _lib.check(self.L.dsim_unet_set_sample_size(self._h, int(side)), "dsim_unet_set_sample_size")
             self.sample_size = int(side)
             self._refresh_tap_shape()
-            self._graphs.clear()
 
     def set_cfg_dedup(self, enable: bool):
         """Opt-in: compute the part of the graph both CFG halves share once (SD1.5 graphs; bit-identical scores)."""
@@ -278,7 +282,7 @@ class UNetEngine:
         """hipGraph path for launch-bound small batches: the ~330 kernel launches of one forward are captured
         once per (n_images, sqrt_abar, sqrt_1m_abar) over static input/output buffers and replayed as one graph
         launch.  dsim_unet_qkv never allocates or synchronises, so plain stream capture works."""
-        key = (shape[0], sa, sb)
+        key = (self.target_block, str(self.target_layer), self.sample_size, _stream_ptr(), shape[0], sa, sb)
         ent = self._graphs.get(key)
         if ent is None:
             st = {"lat": torch.empty_like(latents), "nz": torch.empty_like(noise), "ctx": torch.empty_like(ctx),

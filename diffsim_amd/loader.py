@@ -27,27 +27,53 @@ from . import text as T
 from .config import SD15, SDXL, VAE_SD15, DIT_XL2, DiTConfig, UNetConfig, VAEConfig
 
 
-def _find_weights(folder: str) -> str:
-    """The safetensors file of a diffusers / transformers component folder (fp32 name first, then the fp16 variant)."""
-    for name in ("diffusion_pytorch_model.safetensors", "model.safetensors", "diffusion_pytorch_model.fp16.safetensors",
-                 "model.fp16.safetensors"):
+_WEIGHT_NAMES = ("diffusion_pytorch_model.safetensors", "model.safetensors", "diffusion_pytorch_model.fp16.safetensors",
+                 "model.fp16.safetensors")
+
+
+def _find_weights(folder: str):
+    """The safetensors file(s) of a diffusers / transformers component folder: a single file (fp32 name first, then the
+    fp16 variant), or every shard a ``*.safetensors.index.json`` lists (sharded checkpoints: ...-00001-of-0000N.safetensors)."""
+    for name in _WEIGHT_NAMES:
         p = os.path.join(folder, name)
         if os.path.exists(p):
-            return p
+            return [p]
+    idx = sorted(glob.glob(os.path.join(folder, "*.safetensors.index.json")))
+    if idx:
+        with open(idx[0]) as f:
+            shards = sorted(set(json.load(f)["weight_map"].values()))
+        paths = [os.path.join(folder, s) for s in shards]
+        missing = [p for p in paths if not os.path.exists(p)]
+        if missing:
+            raise FileNotFoundError(f"{idx[0]} lists shards that are not there: {missing}")
+        return paths
     cands = sorted(glob.glob(os.path.join(folder, "*.safetensors")))
     if not cands:
         raise FileNotFoundError(f"no .safetensors file under {folder}")
-    return cands[0]
+    if len(cands) > 1:
+        raise FileNotFoundError(f"{folder} holds several .safetensors files and no *.safetensors.index.json saying which belong "
+                                f"together: {[os.path.basename(c) for c in cands]}")
+    return cands
 
 
 def load_state_dict(folder: str) -> Dict[str, torch.Tensor]:
     from safetensors.torch import load_file
-    return load_file(_find_weights(folder), device="cpu")
+    sd: Dict[str, torch.Tensor] = {}
+    for p in _find_weights(folder):
+        part = load_file(p, device="cpu")
+        dup = set(part) & set(sd)
+        if dup:
+            raise ValueError(f"{p} repeats keys of an earlier shard: {sorted(dup)[:3]} ...")
+        sd.update(part)
+    return sd
 
 
 def _json(folder: str) -> dict:
     p = os.path.join(folder, "config.json")
-    return json.load(open(p)) if os.path.exists(p) else {}
+    if not os.path.exists(p):
+        return {}
+    with open(p) as f:
+        return json.load(f)
 
 
 def unet_config_from_json(j: dict, default: UNetConfig) -> UNetConfig:
@@ -123,7 +149,13 @@ class LazyTokenizer:
 
 
 def _torch_dtype(name: str) -> torch.dtype:
-    return {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.bfloat16}[name]
+    """Compute dtype of the kernels: bf16 (the MFMA path) or fp32 (parity mode).  There is no fp16 kernel mode; the
+    reference's fp16 *pipeline arithmetic* is --noise_dtype fp16."""
+    try:
+        return {"bf16": torch.bfloat16, "fp32": torch.float32}[name]
+    except KeyError:
+        raise ValueError(f"--dtype {name!r}: the engine computes in bf16 or fp32 (for the reference's fp16 pipeline "
+                         f"arithmetic use --noise_dtype fp16)") from None
 
 
 def load_diffsim(model_path: str, dtype: str = "bf16", device: str = "cuda", noise_dtype=torch.float32, **kw):

@@ -26,22 +26,69 @@ def free_port() -> int:
     return p
 
 
-def spawn_ranks(n: int, cmd: Sequence[str]) -> int:
+def spawn_ranks(n: int, cmd: Sequence[str], poll_s: float = 0.2, grace_s: float = 10.0) -> int:
     """Start `n` fresh rank processes of `cmd` on this node (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
-    environment, rendezvous on 127.0.0.1) and wait for them; returns the first non-zero exit code.  The caller must
-    not have touched the GPU: nothing is exec'ed from a GPU-initialised process, the ranks are plain children."""
+    environment, rendezvous on 127.0.0.1) and supervise them; returns the first non-zero exit code.
+
+    All ranks are polled together: when one exits non-zero (a bad image path in its shard, out of memory, a missing
+    weight), the others -- which would otherwise sit in their next collective until the RCCL / gloo timeout -- are
+    terminated (SIGTERM, then SIGKILL after `grace_s`) and that rank's code is returned at once.  SIGINT / SIGTERM to
+    this process tear the ranks down the same way (no orphan GPU processes behind a Ctrl-C).  The caller must not have
+    touched the GPU: nothing is exec'ed from a GPU-initialised process, the ranks are plain children."""
+    import signal
+    import time
     env0 = dict(os.environ)
     env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env0["MASTER_ADDR"] = "127.0.0.1"
     env0["MASTER_PORT"] = str(free_port())
     env0["WORLD_SIZE"] = env0["LOCAL_WORLD_SIZE"] = str(n)
     procs = [subprocess.Popen(list(cmd), env=dict(env0, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.monotonic() + grace_s
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.0, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    got = []
+
+    def on_signal(signum, _frame):
+        got.append(signum)
+
+    old = {}
+    for sig in (signal.SIGINT, signal.SIGTERM):
+        try:
+            old[sig] = signal.signal(sig, on_signal)
+        except ValueError:          # not the main thread: no handlers, the polling below still works
+            pass
     rc = 0
-    for r, p in enumerate(procs):
-        c = p.wait()
-        if c != 0:
-            print(f"rank {r} exited with code {c}", file=sys.stderr, flush=True)
-            rc = rc or c
+    try:
+        pending = set(range(n))
+        while pending:
+            if got:
+                print(f"signal {got[0]}: stopping {len(pending)} rank(s)", file=sys.stderr, flush=True)
+                stop_all()
+                return 128 + got[0]
+            for r in sorted(pending):
+                c = procs[r].poll()
+                if c is None:
+                    continue
+                pending.discard(r)
+                if c != 0:
+                    print(f"rank {r} exited with code {c}; stopping the other ranks", file=sys.stderr, flush=True)
+                    stop_all()
+                    return c
+            if pending:
+                time.sleep(poll_s)
+    finally:
+        for sig, h in old.items():
+            signal.signal(sig, h)
     return rc
 
 

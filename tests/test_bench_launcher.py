@@ -47,9 +47,60 @@ def test_mislabelled_runs_are_refused():
     e = dict(_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--selftest-launch"], capture_output=True, text=True, env=e, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr and "{" not in r.stdout
-    # more GPUs asked for than visible (none here): no silent 1-GPU run
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "8"], capture_output=True, text=True, env=_env(), timeout=120)
+    # more GPUs asked for than visible (none here): no silent 1-GPU run.  The parent never touches the HIP runtime; the
+    # ranks refuse themselves ("needs a GPU" / "rank r needs GPU k, only n visible") and the supervisor stops the rest
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8"], capture_output=True, text=True, env=_env(), timeout=300)
     if r.returncode == 0:
         assert _line(r.stdout)["n_gpus"] == 8          # only on a real 8-GPU node
     else:
-        assert "visible" in r.stderr and "{" not in r.stdout
+        assert ("visible" in r.stderr or "needs a GPU" in r.stderr) and "{" not in r.stdout
+        assert "stopping the other ranks" in r.stderr
+
+
+def test_spawn_ranks_stops_the_survivors_when_one_rank_dies(tmp_path):
+    """parallel.spawn_ranks polls all ranks: rank 1 exits 7 at once, rank 0 would sleep a minute (a stand-in for a rank
+    waiting in its next collective) -- the launcher must return 7 within seconds and leave no child behind."""
+    import time
+    sys.path.insert(0, ROOT)
+    from diffsim_amd import parallel
+    script = tmp_path / "rank.py"
+    pidfile = tmp_path / "pid0"
+    script.write_text(
+        "import os, sys, time\n"
+        "if os.environ['RANK'] == '1':\n"
+        "    sys.exit(7)\n"
+        f"open({str(pidfile)!r}, 'w').write(str(os.getpid()))\n"
+        "time.sleep(60)\n")
+    t0 = time.monotonic()
+    rc = parallel.spawn_ranks(2, [sys.executable, str(script)], poll_s=0.05, grace_s=5.0)
+    assert rc == 7 and time.monotonic() - t0 < 20
+    for _ in range(100):                       # rank 0 may not have written its pid before it was stopped
+        if pidfile.exists():
+            break
+        time.sleep(0.01)
+    if pidfile.exists():
+        pid = int(pidfile.read_text())
+        time.sleep(0.2)
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except OSError:
+            alive = False
+        assert not alive
+
+
+def test_spawn_ranks_forwards_sigterm(tmp_path):
+    """SIGTERM to the launching process tears its ranks down (no orphan GPU processes behind a Ctrl-C / kill)."""
+    import signal
+    import time
+    script = tmp_path / "rank.py"
+    script.write_text("import time\ntime.sleep(120)\n")
+    launcher = tmp_path / "launch.py"
+    launcher.write_text(
+        f"import sys\nsys.path.insert(0, {ROOT!r})\nfrom diffsim_amd import parallel\n"
+        f"sys.exit(parallel.spawn_ranks(2, [sys.executable, {str(script)!r}], poll_s=0.05, grace_s=5.0))\n")
+    p = subprocess.Popen([sys.executable, str(launcher)], env=_env())
+    time.sleep(3.0)                            # import torch + start the ranks
+    p.send_signal(signal.SIGTERM)
+    rc = p.wait(timeout=30)
+    assert rc == 128 + signal.SIGTERM

@@ -161,3 +161,29 @@ def test_public_header_is_plain_c99(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
                         "-fsyntax-only", str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_loader_reads_sharded_checkpoints_and_refuses_ambiguity(tmp_path):
+    """loader.load_state_dict: a *.safetensors.index.json checkpoint is merged from all its shards; several unindexed
+    files, a missing shard, repeated keys and the removed 'fp16' compute-dtype alias raise instead of loading a part."""
+    import json as _json
+    import torch
+    from safetensors.torch import save_file
+    from diffsim_amd import loader
+    d = tmp_path / "unet"
+    d.mkdir()
+    save_file({"a.weight": torch.ones(2, 2)}, str(d / "diffusion_pytorch_model-00001-of-00002.safetensors"))
+    save_file({"b.weight": torch.zeros(3)}, str(d / "diffusion_pytorch_model-00002-of-00002.safetensors"))
+    with pytest.raises(FileNotFoundError, match="several"):
+        loader.load_state_dict(str(d))
+    idx = {"weight_map": {"a.weight": "diffusion_pytorch_model-00001-of-00002.safetensors",
+                          "b.weight": "diffusion_pytorch_model-00002-of-00002.safetensors"}}
+    (d / "diffusion_pytorch_model.safetensors.index.json").write_text(_json.dumps(idx))
+    sd = loader.load_state_dict(str(d))
+    assert sorted(sd) == ["a.weight", "b.weight"] and sd["a.weight"].shape == (2, 2)
+    (d / "diffusion_pytorch_model-00002-of-00002.safetensors").unlink()
+    with pytest.raises(FileNotFoundError, match="not there"):
+        loader.load_state_dict(str(d))
+    with pytest.raises(ValueError, match="bf16 or fp32"):
+        loader._torch_dtype("fp16")
+    assert loader._json(str(tmp_path / "nowhere")) == {}

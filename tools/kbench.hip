@@ -133,13 +133,19 @@ static void bench_attn(const char* name, int B, int Bkv, int H, int Nq, int Nk, 
     else { a.q = q; a.ldq = C; a.k = kv; a.v = (char*)kv + C * 2; a.ldk = 2 * C; }
     a.out = out; a.ldo = C; a.B = B; a.Bkv = Bkv; a.H = H; a.Nq = Nq; a.Nk = Nk; a.D = D;
     int st = DSIM_OK;
-    a.xcd_remap = 0;
-    const float ms0 = t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters);
-    a.xcd_remap = 1;
-    const float ms = t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters);
-    const float ms0b = (a.xcd_remap = 0, t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
+    const int rounds = getenv("KB_ROUNDS") ? atoi(getenv("KB_ROUNDS")) : 5;
+    std::vector<float> m0, m1;
+    for (int r = 0; r < rounds; ++r) {            // interleaved rounds: plain block order / XCD-aware order
+        a.xcd_remap = 0;
+        m0.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
+        a.xcd_remap = 1;
+        m1.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
+    }
+    std::sort(m0.begin(), m0.end()); std::sort(m1.begin(), m1.end());
+    const float ms = m1[rounds / 2];
     const double fl = 4.0 * B * H * (double)Nq * Nk * D;
-    printf("%-28s B=%3d H=%d Nq=%5d Nk=%5d D=%3d  plain %8.3f / %8.3f ms | xcd-aware %8.3f ms  %7.1f TF/s  st=%d\n", name, B, H, Nq, Nk, D, ms0, ms0b, ms, fl / ms / 1e9, st);
+    printf("%-28s B=%3d H=%d Nq=%5d Nk=%5d D=%3d  plain %8.3f/%8.3f ms | xcd-aware min/median %8.3f/%8.3f ms  %7.1f TF/s  st=%d\n", name, B, H,
+           Nq, Nk, D, m0[0], m0[rounds / 2], m1[0], ms, fl / ms / 1e9, st);
     HC(hipFree(q)); if (kv) HC(hipFree(kv)); HC(hipFree(out));
 }
 

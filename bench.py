@@ -359,14 +359,13 @@ def headline(a, world, rank, dev):
         from diffsim_amd.engine import VAEEncoder
         vae = VAEEncoder(C.VAE_SD15, S.make_state_dict(C.VAE_SD15, seed=1), dtype, str(dev))
         imgs = torch.cat([torch.cat(S.make_image_pair(rank * bp + i, 512)) for i in range(bp)]).to(dev)   # [2*bp,3,512,512]
-        eps = torch.cat([noise[0], noise[1]] * bp).to(dev)         # the two VAE-sample draws (reference order)
+        eps = torch.cat([noise[0], noise[1]] * bp).to(dev).contiguous()         # the two VAE-sample draws (reference order)
+        from diffsim_amd.engine import latent_sample
 
     def step(i=0):
         if a.pixels_in:
-            mom = vae.moments(imgs)
-            mean, logvar = mom.chunk(2, dim=1)
-            z = (mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * eps) * 0.18215
-            q, k, v = eng.qkv(z.contiguous(), nz, sa, sb, ctx, out=qkv)
+            z = latent_sample(vae.moments(imgs), eps, 0.18215)         # posterior sample + scaling: one HIP launch (dsim_latent_sample)
+            q, k, v = eng.qkv(z, nz, sa, sb, ctx, out=qkv)
         elif NS == 1:
             q, k, v = eng.qkv(lat_all[i % NB], nz, sa, sb, ctx, out=qkv)
         else:

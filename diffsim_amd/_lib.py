@@ -83,12 +83,15 @@ SYMBOLS = {
     "dsim_vae_finalize": (_i, [_vp, _vp]),
     "dsim_vae_workspace_bytes": (_sz, [_vp, _i, _i]),
     "dsim_vae_encode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "dsim_image_preprocess": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "dsim_latent_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "dsim_dit_create": (_i, [C.POINTER(DiTCfgC), C.POINTER(_vp)]),
     "dsim_dit_destroy": (None, [_vp]),
     "dsim_dit_load_weight": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(C.c_int64), _i]),
     "dsim_dit_finalize": (_i, [_vp, _vp]),
     "dsim_dit_set_conditioning": (_i, [_vp, _i, _i, _i, _vp]),
     "dsim_dit_set_attention": (_i, [_vp, _i]),
+    "dsim_dit_set_tap": (_i, [_vp, _i]),
     "dsim_dit_profile": (_i, [_vp, _i]),
     "dsim_dit_profile_count": (_i, [_vp]),
     "dsim_dit_profile_get": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

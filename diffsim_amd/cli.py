@@ -1,10 +1,10 @@
 """Command-line driver: the reference's benchmark loops on the MI355X engine.
 
-``python -m diffsim_amd --dataset cute|nights --metric diffsim|diffsim_xl|dit --model_path <dir> --image_path <dir> ...``
+``python -m diffsim_amd --dataset cute|nights|sref --metric diffsim|diffsim_xl|dit --model_path <dir> --image_path <dir> ...``
 
 Flags of the reference drivers (``/root/reference/argprocess.py:5-18``) keep their names, meaning and defaults;
-``--dataset`` selects which of the reference's loops runs (``cute_main.py:48-226`` or ``night_main.py:24-173`` -- separate
-scripts there), ``--model_path / --dtype / --batch / --ngpu / --noise_dtype`` are additions of this build (the reference
+``--dataset`` selects which of the reference's loops runs (``cute_main.py:48-226``, ``night_main.py:24-173`` or
+``style_main.py:24-196`` -- separate scripts there), ``--model_path / --dtype / --batch / --ngpu / --noise_dtype`` are additions of this build (the reference
 hard-codes NAS checkpoint paths, ``cute_main.py:25-31``, fp16 and one GPU, ``cute_main.sh:1``).
 
 Multi-GPU (``--ngpu N``): the parent starts N rank processes before anything touches the GPU; triplets are sharded
@@ -40,8 +40,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--use_text_attn", action="store_true")
     p.add_argument("--seed", type=int, default=2333)
     # additions of this build
-    p.add_argument("--dataset", type=str, choices=["cute", "nights"], default="cute",
-                   help="which reference loop to run: cute_main.py (class/instance/lighting tree) or night_main.py (data.csv)")
+    p.add_argument("--dataset", type=str, choices=["cute", "nights", "sref"], default="cute",
+                   help="which reference loop to run: cute_main.py (class/instance/lighting tree), night_main.py (data.csv) or "
+                        "style_main.py (Sref / InstantStyle: one folder per style, 2000 sampled experiments)")
+    p.add_argument("--experiments", type=int, default=2000, help="--dataset sref: sampled experiments (style_main.py:64)")
     p.add_argument("--model_path", type=str, default=None, help="diffusers-layout checkpoint directory (unet/, vae/, text_encoder/, tokenizer/)")
     p.add_argument("--dtype", type=str, choices=["bf16", "fp32"], default="bf16", help="engine compute dtype (fp32 = parity mode)")
     p.add_argument("--noise_dtype", type=str, choices=["fp32", "fp16"], default="fp32",
@@ -97,6 +99,32 @@ def cute_triplets(image_path: str, seed: int) -> List[Tuple[str, str, str, str]]
     return out
 
 
+# ---- the Sref / InstantStyle walk (style_main.py:48-76) ----------------------------------------------------------------
+def sref_triplets(image_path: str, seed: int, prompt: str, experiments: int = 2000) -> List[Tuple[str, str, str, str]]:
+    """(A, B, C, prompt) of the style benchmark: every sub-folder with at least two images is a style; each experiment
+    draws two different styles, two images of the first (A, B) and one of the second (C).  The ``random`` calls are the
+    reference's, in its order (seeded like it, style_main.py:27), so the same tree gives the same experiments."""
+    random.seed(seed)
+    ext = (".png", ".jpg", ".jpeg")
+    styles = {}
+    for root, dirs, _files in os.walk(image_path):
+        for d in dirs:
+            full = os.path.join(root, d)
+            ims = [os.path.join(full, f) for f in os.listdir(full) if f.endswith(ext)]
+            if len(ims) >= 2:
+                styles[full] = ims
+    names = list(styles.keys())
+    out = []
+    for _ in range(experiments):
+        if len(names) < 2:
+            continue
+        dir_a, dir_c = random.sample(names, 2)
+        a, b = random.sample(styles[dir_a], 2)
+        c = random.choice(styles[dir_c])
+        out.append((a, b, c, prompt))
+    return out
+
+
 def cute_counts(s_ab, s_ac, similarity: str) -> Tuple[int, int]:
     """correct / correct_2x of cute_main.py:196-205 (a NaN score compares False: counted wrong, as there)."""
     if similarity == "mse":
@@ -130,8 +158,10 @@ def run(args) -> int:
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         import torch.distributed as dist
+        from .parallel import pin_to_gpu_numa
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        pin_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")))       # image decode threads next to this rank's GPU
         dist.init_process_group("nccl")
     scorer = build_scorer(args)
     layer = args.target_layer if isinstance(args.target_layer, list) else [args.target_layer]
@@ -141,6 +171,8 @@ def run(args) -> int:
     if args.dataset == "nights":
         rows = H.read_nights_csv(args.image_path)
         trip = [(r["ref"], r["left"], r["right"], r["prompt"]) for r in rows]
+    elif args.dataset == "sref":
+        trip = sref_triplets(args.image_path, args.seed, args.prompt, args.experiments)
     else:
         trip = cute_triplets(args.image_path, args.seed)
     s_ab, s_ac, bad = H.score_path_triplets(scorer, trip, args.image_size, args.target_block, layer, args.target_step, args.seed,
@@ -154,12 +186,17 @@ def run(args) -> int:
             print(f"Final validation accuracy: {acc:.2f}%")
         else:
             correct, correct2 = cute_counts(s_ab.cpu(), s_ac.cpu(), args.similarity)
-            print(f"Total comparisons: {total}")
-            if total > 0:
+            if total > 0 and args.dataset == "sref":           # style_main.py:186-193
+                print(f"Total comparisons: {total}")
+                print(f"Accuracy: {correct / total * 100:.2f}%")
+                print(f"2x Accuracy: {correct2 / total * 100:.2f}%")
+            elif total > 0:                                     # cute_main.py:216-224
+                print(f"Total comparisons: {total}")
                 print(f"Total {total}; Correct {correct}; Correct 2x {correct2}")
                 print(f"Accuracy: {correct / total * 100}%")
                 print(f"2x Accuracy: {correct2 / total * 100}%")
             else:
+                print("Total comparisons: 0")
                 print("No valid comparisons were made.")
     if world > 1:
         import torch.distributed as dist

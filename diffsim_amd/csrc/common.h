@@ -103,6 +103,11 @@ int convert_f32_to(const float* src, void* dst, int dtype, size_t n, hipStream_t
 // out[2b], out[2b+1] = in[b]: a batch element becomes its two classifier-free-guidance copies (bytes_per_elem % 16 == 0)
 int dup_batch(const void* in, void* out, int n_batch, size_t bytes_per_elem, hipStream_t s);
 
+// uint8 HWC pixels -> process_image's normalised NCHW f32 (half: rounded through fp16); VAE posterior sample -- pack.hip
+int image_preprocess(const unsigned char* hwc, float* out, int n, int H, int W, int half, hipStream_t s);
+int latent_sample(const float* moments, const float* eps, float* out, int n_out, int first, int stride, int C, int hw, int eps_n,
+                  float sf, int round16, hipStream_t s);
+
 // norms -- norm.hip
 size_t groupnorm_scratch_bytes(int B, int groups);
 int groupnorm_passes(int C0, int C1, int HW, int groups, int dtype);    // 2 (one-pass form) or 3: algorithmic tensor passes

@@ -276,11 +276,15 @@ int dsim_dit_set_conditioning(dsim_dit* h, int t_model, int y0, int y1, void* st
     for (int half = 0; half < 2; ++half) {
         float* cv = h->cvec + (size_t)half * D;
         hipLaunchKernelGGL(add_table_row_kernel, dim3((D + 255) / 256), dim3(256), 0, s, temb, (const float*)tab->p, ys[half], cv, D);
-        for (int blk = 0; blk <= c.tap_layer; ++blk) {
+        // every block whose weights are loaded, not only those up to the current tap: dsim_dit_set_tap may move it later
+        for (int blk = 0; blk < c.depth; ++blk) {
             const std::string b = "blocks." + std::to_string(blk) + ".adaLN_modulation.1.";
             const Packed* aw = h->find(b + "weight");
             const Packed* ab = h->find(b + "bias");
-            if (!aw || !ab) return DSIM_ERR_MISSING_WEIGHT;
+            if (!aw || !ab) {
+                if (blk <= c.tap_layer) return DSIM_ERR_MISSING_WEIGHT;
+                break;
+            }
             CK(gemv_f32(aw->p, DSIM_F32, ab->p, DSIM_F32, cv, m6, 6 * D, D, 1, s));        // Linear(SiLU(c))
             for (int j = 0; j < 6; ++j)
                 DSIM_HIP_CHECK(hipMemcpyAsync(h->mod + ((((size_t)blk * 6 + j) * 2) + half) * D, m6 + (size_t)j * D, (size_t)D * 4,
@@ -289,6 +293,19 @@ int dsim_dit_set_conditioning(dsim_dit* h, int t_model, int y0, int y1, void* st
     }
     DSIM_HIP_CHECK(hipGetLastError());
     h->cond_set = true;
+    return DSIM_OK;
+}
+
+int dsim_dit_set_tap(dsim_dit* h, int tap_layer) {
+    if (!h || tap_layer < 0 || tap_layer >= h->cfg.depth) return DSIM_ERR_INVALID;
+    if (!h->finalized) return DSIM_ERR_STATE;
+    const int old = h->cfg.tap_layer;
+    if (tap_layer == old) return DSIM_OK;
+    h->cfg.tap_layer = tap_layer;
+    Arena ar;                                   // every parameter up to the new tap must have been loaded: dry walk
+    DWalk w{h, &ar, nullptr, 1, false};
+    const int st = w.go(nullptr, nullptr, 0.f, 0.f);
+    if (st != DSIM_OK) { h->cfg.tap_layer = old; return st; }
     return DSIM_OK;
 }
 

@@ -355,4 +355,70 @@ int convert_f32_to(const float* src, void* dst, int dtype, size_t n, hipStream_t
     return DSIM_OK;
 }
 
+// ---- host-adjacent arithmetic of the path, kept on the device so that decoded pixels are the only thing the host produces ----
+namespace {
+
+// process_image after the resize (/root/reference/diffsim/diffsim.py:31-41): uint8 HWC -> /255 -> (x - 0.5) / 0.5 -> NCHW.
+// Plain IEEE f32 operations in numpy's order, so the result is bit-identical to the host path (asserted against golden G1);
+// half = 1: the SD1.5 pipeline's fp16 image cast (diffsim.py:93) folded in, stored as f32 values that are exactly fp16.
+__global__ void image_preprocess_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, int HW, size_t total, int half) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread per pixel
+    if (i >= total) return;
+    const size_t n = i / HW, pix = i - n * HW;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = __fdiv_rn((float)src[i * 3 + c], 255.0f);
+        v = __fdiv_rn(__fsub_rn(v, 0.5f), 0.5f);
+        asm volatile("" : "+v"(v));              // (f32 result first, then the fp16 cast: no fused convert)
+        if (half) v = (float)(_Float16)v;
+        dst[(n * 3 + c) * HW + pix] = v;
+    }
+}
+
+// DiagonalGaussianDistribution.sample + scaling (diffusers AutoencoderKL as prepare_image_latents uses it, diffsim.py:92-96):
+// lat = sf * (mean + exp(0.5 * clamp(logvar, -30, 20)) * eps); eps is one draw shared by every image (eps_n = 1) or per image;
+// round16 = 1 rounds the result through fp16 (the fp16 pipeline's latents, diffsim_xl.py:63 / noise_dtype = float16).
+// moments [n][2C][hw]; image j of the batch takes every `stride`-th image starting at `first` (triplets: ref / left / right).
+__global__ void latent_sample_kernel(const float* __restrict__ mom, const float* __restrict__ eps, float* __restrict__ out, int C,
+                                     int hw, int n_out, int first, int stride, int eps_n, float sf, int round16) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = C * hw;
+    if (i >= n_out * per) return;
+    const int j = i / per, r = i - j * per;
+    const float* m = mom + (size_t)(first + j * stride) * 2 * per;
+    const float mean = m[r];
+    float lv = m[per + r];
+    lv = fminf(fmaxf(lv, -30.0f), 20.0f);
+    const float sd = expf(__fmul_rn(0.5f, lv));
+    // separately rounded multiply / add / multiply, as the elementwise tensor expression sf * (mean + std * eps) evaluates
+    // (no fused multiply-add): bit-identical to the host-framework form it replaces
+    float v = __fmul_rn(sf, __fadd_rn(mean, __fmul_rn(sd, eps[(eps_n > 1 ? (size_t)j * per : 0) + r])));
+    // the f32 product is rounded FIRST, then to fp16 (two roundings, as latents.to(float16) does): the opaque copy keeps hipcc
+    // from folding the multiply and the conversion into one v_fma_mix, which rounds the exact product once and lands on the
+    // other side of an fp16 tie
+    asm volatile("" : "+v"(v));
+    if (round16) v = (float)(_Float16)v;
+    out[i] = v;
+}
+
+}  // namespace
+
+int image_preprocess(const unsigned char* hwc, float* out, int n, int H, int W, int half, hipStream_t s) {
+    if (!hwc || !out || n < 1 || H < 1 || W < 1) return DSIM_ERR_INVALID;
+    const size_t total = (size_t)n * H * W;
+    hipLaunchKernelGGL(image_preprocess_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hwc, out, H * W, total, half);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+
+int latent_sample(const float* moments, const float* eps, float* out, int n_out, int first, int stride, int C, int hw, int eps_n,
+                  float sf, int round16, hipStream_t s) {
+    if (!moments || !eps || !out || n_out < 1 || C < 1 || hw < 1 || stride < 1 || first < 0) return DSIM_ERR_INVALID;
+    const int total = n_out * C * hw;
+    hipLaunchKernelGGL(latent_sample_kernel, dim3((total + 255) / 256), dim3(256), 0, s, moments, eps, out, C, hw, n_out, first, stride,
+                       eps_n, sf, round16);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+
 }  // namespace dsim

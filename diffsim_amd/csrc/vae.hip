@@ -312,4 +312,13 @@ int dsim_vae_encode(dsim_vae* h, const float* images, int n_images, int image_si
     return ar.overflow ? DSIM_ERR_WORKSPACE : DSIM_OK;
 }
 
+int dsim_image_preprocess(const unsigned char* pixels_hwc, float* out, int n, int H, int W, int to_half, void* stream) {
+    return image_preprocess(pixels_hwc, out, n, H, W, to_half != 0, (hipStream_t)stream);
+}
+
+int dsim_latent_sample(const float* moments, const float* eps, float* out, int n_out, int first, int stride, int C, int hw,
+                       int eps_n, float scaling_factor, int round_fp16, void* stream) {
+    return latent_sample(moments, eps, out, n_out, first, stride, C, hw, eps_n, scaling_factor, round_fp16 != 0, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -27,7 +27,7 @@ import torch
 from . import scheduler as sched
 from .config import SD15, UNetConfig
 from .engine import UNetEngine, pair_score
-from .image import load_image, process_image
+from .image import host_threads, load_image, process_image, resize_u8
 
 
 def get_generator(seed, device="cpu"):
@@ -89,7 +89,7 @@ class DiffSim:
         self._base: Optional[UNetEngine] = None
         self._engines: Dict[Tuple[str, int], object] = {}
         self._ctx: Dict[str, torch.Tensor] = {}
-        self._pool = ThreadPoolExecutor(max_workers=16)     # host-side image decode / resize
+        self._pool = ThreadPoolExecutor(max_workers=host_threads())     # host-side image decode / resize: cores / ranks of the node
         self._streams: List[torch.cuda.Stream] = []          # side streams of score_latent_pairs
 
     # ------------------------------------------------------------------------------------------
@@ -249,31 +249,32 @@ class DiffSim:
         if vae is not None and hasattr(vae, "moments"):
             # HIP VAE: images decoded on the host thread pool, one encode per chunk of pairs; every pair reseeds the
             # same generator, so its four draws (vaeA, vaeB, noiseA, noiseB) are the same tensors for all pairs
-            from .engine import _LatentDist
+            from .engine import image_preprocess, latent_sample
             g = get_generator(seed, "cpu")
             eps = None
             sf = vae.config.scaling_factor
+            nd = self.noise_dtype
             def submit(i0):
                 paths = [p for ab in pairs[i0:i0 + batch_pairs] for p in ab]
-                return [self._pool.submit(lambda p_=p_: process_image(load_image(p_), img_size)) for p_ in paths]
+                return [self._pool.submit(lambda p_=p_: resize_u8(load_image(p_), img_size)) for p_ in paths]
             starts = list(range(0, len(pairs), batch_pairs))
-            pending = [submit(i0) for i0 in starts[:2]]          # decode runs two chunks ahead of the GPU
+            pending = [submit(i0) for i0 in starts[:2]]          # decode + resize run two chunks ahead of the GPU
             for ci, i0 in enumerate(starts):
-                ims = [f.result() for f in pending.pop(0)]
+                px = torch.cat([f.result() for f in pending.pop(0)])
                 if ci + 2 < len(starts):
                     pending.append(submit(starts[ci + 2]))
-                x = torch.cat(ims).to(vae.device).to(dtype=self.vae_dtype)
-                d = _LatentDist(vae.moments(x))
+                # process_image's arithmetic and the fp16 image cast on the device (bit-identical, dsim_image_preprocess)
+                x = image_preprocess(px.to(vae.device, non_blocking=True), self.vae_dtype == torch.float16)
+                mom = vae.moments(x)
                 if eps is None:
-                    shp = (1,) + tuple(d.mean.shape[1:])
-                    nd = self.noise_dtype
+                    shp = (1, mom.shape[1] // 2) + tuple(mom.shape[2:])
                     eA = torch.randn(shp, generator=g, dtype=nd).float().to(vae.device)
                     eB = torch.randn(shp, generator=g, dtype=nd).float().to(vae.device)
                     nA = torch.randn(shp, generator=g, dtype=nd).float()
                     nB = torch.randn(shp, generator=g, dtype=nd).float()
                     eps = (eA, eB)
-                lA.append((sf * (d.mean[0::2] + d.std[0::2] * eps[0])).to(self.noise_dtype).float())
-                lB.append((sf * (d.mean[1::2] + d.std[1::2] * eps[1])).to(self.noise_dtype).float())
+                lA.append(latent_sample(mom, eps[0], sf, 0, 2, nd == torch.float16))
+                lB.append(latent_sample(mom, eps[1], sf, 1, 2, nd == torch.float16))
             return self.score_latent_pairs(torch.cat(lA), torch.cat(lB), nA, nB, prompt, target_block, target_layer,
                                            target_step, similarity, batch_pairs)
         for pa, pb in pairs:

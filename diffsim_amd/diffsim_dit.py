@@ -29,14 +29,16 @@ class diffsim_DiT:
         self.dtype = torch.bfloat16 if torch_dtype == torch.float16 else torch_dtype
         self.device = torch.device("cuda:0" if device == "cuda" else device)
         self.fp8_attention = fp8_attention      # e4m3 MFMAs for QK^T and PV inside the DiT blocks (opt-in)
-        self._engines: Dict[int, DiTEngine] = {}
+        self._engine: Optional[DiTEngine] = None
 
     def engine(self, layer: int) -> DiTEngine:
-        if layer not in self._engines:
-            self._engines[layer] = DiTEngine(self.cfg, self.state_dict, self.dtype, layer, str(self.device))
+        """The engine with its tap at blocks[layer]: ONE packed weight copy, the tap is moved (dsim_dit_set_tap)."""
+        if self._engine is None:
+            self._engine = DiTEngine(self.cfg, self.state_dict, self.dtype, int(layer), str(self.device))
             if self.fp8_attention:
-                self._engines[layer].set_attention(True)
-        return self._engines[layer]
+                self._engine.set_attention(True)
+        self._engine.set_tap(int(layer))
+        return self._engine
 
     def prepare_image_latents(self, image, generator=None):
         if self.vae is None:

@@ -426,24 +426,70 @@ def op_attention(q, k, v, heads, fp8: bool = False):
     return out
 
 
+# ---- the arithmetic either side of the VAE encoder, on the device ------------------------------------------------
+def image_preprocess(pixels_u8: torch.Tensor, to_half: bool = False) -> torch.Tensor:
+    """pixels u8 cuda [n][H][W][3] (decoded + Lanczos-resized on the host) -> process_image's f32 [n][3][H][W], bit-identical
+    to the numpy arithmetic of /root/reference/diffsim/diffsim.py:31-41; to_half rounds through fp16 (diffsim.py:93)."""
+    L = _lib.lib()
+    _require_cuda(pixels_u8)
+    if pixels_u8.dtype != torch.uint8 or pixels_u8.ndim != 4 or pixels_u8.shape[3] != 3:
+        raise _lib.DsimError("pixels must be uint8 [n][H][W][3]")
+    n, H, W, _ = pixels_u8.shape
+    out = torch.empty((n, 3, H, W), dtype=torch.float32, device=pixels_u8.device)
+    _lib.check(L.dsim_image_preprocess(pixels_u8.contiguous().data_ptr(), out.data_ptr(), n, H, W, int(to_half), _stream_ptr()),
+               "dsim_image_preprocess")
+    return out
+
+
+def latent_sample(moments: torch.Tensor, eps: torch.Tensor, scaling_factor: float, first: int = 0, stride: int = 1,
+                  round_fp16: bool = False) -> torch.Tensor:
+    """scaling_factor * DiagonalGaussianDistribution(moments).sample() with the caller's draw `eps` ((1,C,h,w) shared or
+    (n_out,C,h,w)), for images first, first+stride, ... of `moments` ((n,2C,h,w) f32 cuda) -> (n_out,C,h,w) f32."""
+    L = _lib.lib()
+    moments, eps = moments.contiguous(), eps.contiguous()
+    _require_cuda(moments, eps)
+    n, C2, h, w = moments.shape
+    Cc = C2 // 2
+    n_out = (n - first + stride - 1) // stride
+    if moments.dtype != torch.float32 or eps.dtype != torch.float32 or eps.shape[1:] != (Cc, h, w) or eps.shape[0] not in (1, n_out):
+        raise _lib.DsimError("latent_sample: moments (n,2C,h,w) f32, eps (1|n_out,C,h,w) f32")
+    out = torch.empty((n_out, Cc, h, w), dtype=torch.float32, device=moments.device)
+    _lib.check(L.dsim_latent_sample(moments.data_ptr(), eps.data_ptr(), out.data_ptr(), n_out, first,
+                                    stride, Cc, h * w, eps.shape[0], float(scaling_factor), int(round_fp16), _stream_ptr()),
+               "dsim_latent_sample")
+    return out
+
+
 # ---- VAE encoder (SURVEY.md section 8f row 1) ------------------------------------------------------------
 class _LatentDist:
     """``DiagonalGaussianDistribution`` surface the reference uses: ``.sample(generator)``
-    (diffsim/diffsim.py:94).  mean/logvar live on the device; the noise is drawn with the caller's
-    generator on ITS device (CPU in the reference-CPU-path setting) in the reference's order."""
+    (diffsim/diffsim.py:94).  The moments live on the device; the noise is drawn with the caller's
+    generator on ITS device (CPU in the reference-CPU-path setting) in the reference's order, and
+    mean + exp(0.5 clamp(logvar)) * eps is one launch of dsim_latent_sample -- the same arithmetic the batched paths use,
+    so a per-pair call and a chunked run give bit-identical latents."""
 
     def __init__(self, moments: torch.Tensor, sample_dtype: torch.dtype = torch.float32):
-        self.mean, logvar = moments.chunk(2, dim=1)
-        self.logvar = logvar.clamp(-30.0, 20.0)
-        self.std = torch.exp(0.5 * self.logvar)
+        self.moments = moments
         # dtype of the sample draw: diffusers draws randn_tensor(dtype=parameters.dtype), i.e. fp16 under the
         # reference's fp16 SD1.5 pipeline -- a different random stream from the fp32 draw of the same generator
         self.sample_dtype = sample_dtype
 
+    @property
+    def mean(self) -> torch.Tensor:
+        return self.moments.chunk(2, dim=1)[0]
+
+    @property
+    def logvar(self) -> torch.Tensor:
+        return self.moments.chunk(2, dim=1)[1].clamp(-30.0, 20.0)
+
+    @property
+    def std(self) -> torch.Tensor:
+        return torch.exp(0.5 * self.logvar)
+
     def sample(self, generator=None) -> torch.Tensor:
-        gdev = generator.device if generator is not None else self.mean.device
+        gdev = generator.device if generator is not None else self.moments.device
         eps = torch.randn(self.mean.shape, generator=generator, dtype=self.sample_dtype, device=gdev)
-        return self.mean + self.std * eps.to(self.mean.device, torch.float32)
+        return latent_sample(self.moments.float(), eps.to(self.moments.device, torch.float32), 1.0)
 
     def mode(self) -> torch.Tensor:
         return self.mean
@@ -544,6 +590,7 @@ class DiTEngine:
                   "freq_dim"):
             setattr(c, f, getattr(cfg, f))
         c.compute_dtype, c.tap_layer = _TORCH2DSIM[dtype], int(target_layer)
+        self.target_layer = int(target_layer)
         self.tokens = (cfg.input_size // cfg.patch_size) ** 2
         self.heads, self.head_dim = cfg.num_heads, cfg.hidden_size // cfg.num_heads
         self._h = C.c_void_p()
@@ -566,6 +613,12 @@ class DiTEngine:
             del keep
         self._ws = None
         self._cond = None
+
+    def set_tap(self, layer: int):
+        """Move the tapped block; the packed weights are shared by every --target_layer (dsim_dit_set_tap)."""
+        if int(layer) != self.target_layer:
+            _lib.check(self.L.dsim_dit_set_tap(self._h, int(layer)), "dsim_dit_set_tap")
+            self.target_layer = int(layer)
 
     def set_attention(self, fp8: bool):
         """fp8 (OCP e4m3) MFMA attention in the DiT blocks (BASELINE config 5); bf16 handles only."""

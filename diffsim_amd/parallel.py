@@ -92,6 +92,32 @@ def spawn_ranks(n: int, cmd: Sequence[str], poll_s: float = 0.2, grace_s: float 
     return rc
 
 
+def pin_to_gpu_numa(local_rank: int) -> bool:
+    """Best effort: restrict this rank's host threads (image decode / resize pool included) to the CPUs of the NUMA node its
+    GPU hangs off, so that the eight ranks of a node neither migrate across sockets nor crowd one.  Returns whether it
+    pinned; any missing sysfs entry leaves the affinity alone."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return False
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return False
+        os.sched_setaffinity(0, cpus)
+        return True
+    except Exception:
+        return False
+
+
 def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     """Strided shard: rank r owns items r, r+world, ... (balanced to within one item)."""
     return list(range(rank, n_items, world))

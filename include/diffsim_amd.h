@@ -245,10 +245,27 @@ int    dsim_dit_profile(dsim_dit* h, int enable);
 int    dsim_dit_profile_count(const dsim_dit* h);
 int    dsim_dit_profile_get(dsim_dit* h, int i, char* name, int name_cap, double* flops, double* bytes, double* ms);
 size_t dsim_dit_workspace_bytes(const dsim_dit* h, int n_images);
+/* Move the tap (the block whose attention q,k,v are emitted) without re-packing: ONE weight copy serves every
+ * --target_layer of diffsim_DiT.diffsim_score (diffsim/diffsim_dit.py:100-104 hooks model.blocks[target_layer[0]].attn).
+ * DSIM_ERR_MISSING_WEIGHT if a block up to the new tap was never loaded (the old tap stays).  dsim_dit_set_conditioning
+ * prepares the modulation vectors of every loaded block, so the conditioning survives a move of the tap. */
+int    dsim_dit_set_tap(dsim_dit* h, int tap_layer);
 /* x_t = sqrt_abar*latents + sqrt_1m_abar*noise (DDIM add_noise at t = target_step, diffsim_dit.py:63-72);
  * q,k,v (out): compute dtype [n_images][2][tokens][heads*head_dim] */
 int    dsim_dit_qkv(dsim_dit* h, const float* latents, const float* noise, float sqrt_abar, float sqrt_1m_abar,
                     int n_images, void* q, void* k, void* v, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- the arithmetic either side of the VAE encoder, on the device (the host only decodes and resizes) ----
+ * dsim_image_preprocess: what process_image does after its Lanczos resize (diffsim/diffsim.py:31-41): pixels u8 [n][H][W][3] ->
+ *   f32 [n][3][H][W] = (p / 255 - 0.5) / 0.5 in IEEE f32, bit-identical to the numpy path; to_half = 1 additionally rounds
+ *   through fp16 (the SD1.5 pipeline's `image.to(dtype=float16)`, diffsim.py:93).
+ * dsim_latent_sample: `scaling_factor * latent_dist.sample()` of prepare_image_latents (diffsim.py:92-96): out[j] =
+ *   sf * (mean + exp(0.5 clamp(logvar, -30, 20)) * eps) for image first + j * stride of `moments` ([n][2C][hw], dsim_vae_encode's
+ *   output); eps f32 [eps_n][C][hw] drawn by the CALLER's generator (eps_n = 1: one draw shared by all, as every reference call
+ *   reseeds; or one per output image); round_fp16 = 1 rounds the latents through fp16 (diffsim_xl.py:63, the fp16 pipelines). */
+int dsim_image_preprocess(const unsigned char* pixels_hwc, float* out, int n, int H, int W, int to_half, void* stream);
+int dsim_latent_sample(const float* moments, const float* eps, float* out, int n_out, int first, int stride, int C, int hw,
+                       int eps_n, float scaling_factor, int round_fp16, void* stream);
 
 /* ---- single-operator entry points (kernel-level parity tests and micro-benchmarks) -----
  * x: dtype [M][K] (or NHWC image for the conv forms); w: diffusers-layout f32 weight.      */

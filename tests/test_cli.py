@@ -111,3 +111,39 @@ def test_cli_builds_the_object_graph_and_fails_loudly_without_gpu(tmp_path):
     for bad in (["--metric", "clip_i"], ["--ip_adapter"], ["--model_path", ""]):
         with pytest.raises(SystemExit):
             cli.main([a for a in argv if a not in ("--metric", "diffsim")] + bad if bad[0] == "--metric" else argv + bad)
+
+
+def test_sref_triplet_walk(tmp_path):
+    """--dataset sref (BASELINE config 4's "Sref style pairs"): the style_main.py:48-76 experiment sampler -- every folder
+    with >= 2 images is a style; per experiment random.sample(styles, 2), random.sample(images of the first, 2),
+    random.choice(images of the second), seeded with --seed.  Checked against that call sequence stated directly."""
+    import random
+    from PIL import Image
+    root = str(tmp_path)
+    for s in range(5):
+        d = os.path.join(root, "group%d" % (s % 2), "style%d" % s)
+        os.makedirs(d)
+        for i in range(3 if s else 1):                 # style0 has one image only: not a style
+            Image.new("RGB", (8, 8), (s * 40, i * 60, 7)).save(os.path.join(d, "im%d.png" % i))
+    t = cli.sref_triplets(root, 2333, "High quality image", 50)
+    assert len(t) == 50 and t == cli.sref_triplets(root, 2333, "High quality image", 50)
+    assert t != cli.sref_triplets(root, 1, "High quality image", 50)
+    for a, b, c, prompt in t:
+        assert os.path.dirname(a) == os.path.dirname(b) and a != b and os.path.dirname(c) != os.path.dirname(a)
+        assert "style0" not in a and "style0" not in c and prompt == "High quality image"
+    # the reference's sequence of random calls over the same os.walk order
+    random.seed(2333)
+    styles = {}
+    for r, dirs, _ in os.walk(root):
+        for d in dirs:
+            full = os.path.join(r, d)
+            ims = [os.path.join(full, f) for f in os.listdir(full) if f.endswith((".png", ".jpg", ".jpeg"))]
+            if len(ims) >= 2:
+                styles[full] = ims
+    names = list(styles)
+    for k in range(50):
+        da, dc = random.sample(names, 2)
+        a, b = random.sample(styles[da], 2)
+        assert t[k][:3] == (a, b, random.choice(styles[dc]))
+    args = cli.arg_parse(["--dataset", "sref", "--metric", "diffsim_xl", "--target_layer", "0", "0", "0"])
+    assert args.experiments == 2000 and args.target_layer == [0, 0, 0]

@@ -50,6 +50,9 @@ def build_parser() -> argparse.ArgumentParser:
                    help="generator draws / add_noise arithmetic: fp32 pipeline or the reference's literal fp16 pipeline")
     p.add_argument("--batch", type=int, default=10, help="triplets per engine batch")
     p.add_argument("--ngpu", type=int, default=1, help="GPUs of this node to shard the triplets over (one process each)")
+    p.add_argument("--decode_procs", type=str, default="auto",
+                   help="worker processes that decode + resize the image files ahead of the GPU: a number, 0 = threads of this "
+                        "process, auto = host cores / ranks of the node")
     p.add_argument("--fp8_attention", action="store_true", help="--metric dit: e4m3 MFMA attention")
     p.add_argument("--dedup_cfg", action="store_true",
                    help="--metric diffsim: compute what the two CFG halves share once per image (bit-identical scores, ~6 %% faster)")
@@ -163,6 +166,7 @@ def run(args) -> int:
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         pin_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")))       # image decode threads next to this rank's GPU
         dist.init_process_group("nccl")
+    os.environ.setdefault("DSIM_DECODE_PROCS", str(args.decode_procs))      # the scorers' DecodePool default
     scorer = build_scorer(args)
     layer = args.target_layer if isinstance(args.target_layer, list) else [args.target_layer]
     if rank == 0:

@@ -27,7 +27,7 @@ import torch
 from . import scheduler as sched
 from .config import SD15, UNetConfig
 from .engine import UNetEngine, pair_score
-from .image import host_threads, load_image, process_image, resize_u8
+from .image import DecodePool, host_threads, load_image, process_image
 
 
 def get_generator(seed, device="cpu"):
@@ -56,7 +56,7 @@ class DiffSim:
                  unet_config: UNetConfig = SD15, state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  vae=None, encode_prompt: Optional[Callable[[str], torch.Tensor]] = None,
                  vae_dtype=torch.float16, use_graphs: bool = False, noise_dtype=torch.float32, dedup_cfg: bool = False,
-                 fusion: Optional[int] = None):
+                 fusion: Optional[int] = None, decode_procs: Optional[int] = None):
         if ip_adapter:
             raise NotImplementedError("IP-Adapter mode is out of scope (SURVEY.md section 2 row 3)")
         if state_dict is None:
@@ -90,6 +90,9 @@ class DiffSim:
         self._engines: Dict[Tuple[str, int], object] = {}
         self._ctx: Dict[str, torch.Tensor] = {}
         self._pool = ThreadPoolExecutor(max_workers=host_threads())     # host-side image decode / resize: cores / ranks of the node
+        # files-in paths: decode + Lanczos resize run ahead of the GPU in worker processes (decode_procs > 0; None = the
+        # DSIM_DECODE_PROCS environment default) or threads (0); started lazily, on the first path batch
+        self._decode = DecodePool(decode_procs)
         self._streams: List[torch.cuda.Stream] = []          # side streams of score_latent_pairs
 
     # ------------------------------------------------------------------------------------------
@@ -255,12 +258,11 @@ class DiffSim:
             sf = vae.config.scaling_factor
             nd = self.noise_dtype
             def submit(i0):
-                paths = [p for ab in pairs[i0:i0 + batch_pairs] for p in ab]
-                return [self._pool.submit(lambda p_=p_: resize_u8(load_image(p_), img_size)) for p_ in paths]
+                return self._decode.submit([p for ab in pairs[i0:i0 + batch_pairs] for p in ab], img_size)
             starts = list(range(0, len(pairs), batch_pairs))
             pending = [submit(i0) for i0 in starts[:2]]          # decode + resize run two chunks ahead of the GPU
             for ci, i0 in enumerate(starts):
-                px = torch.cat([f.result() for f in pending.pop(0)])
+                px = DecodePool.gather(pending.pop(0))
                 if ci + 2 < len(starts):
                     pending.append(submit(starts[ci + 2]))
                 # process_image's arithmetic and the fp16 image cast on the device (bit-identical, dsim_image_preprocess)

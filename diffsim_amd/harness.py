@@ -23,7 +23,7 @@ import torch
 
 from .diffsim import DiffSim, _norm_layer, get_generator
 from .engine import pair_score
-from .image import host_threads, load_image, process_image
+from .image import DecodePool, load_image, process_image
 from .parallel import gather_scores, shard_triplets
 
 
@@ -157,7 +157,6 @@ def score_path_triplets(scorer, triplets: Sequence[Tuple[str, str, str, str]], i
     (dsim_image_preprocess / dsim_latent_sample), bit-identically to the per-pair path.  Returns (s_ab, s_ac, n_nonfinite):
     length-len(triplets) f32 tensors on every rank and the number of NaN/inf pair scores (NaN guard)."""
     from .engine import image_preprocess, latent_sample
-    from .image import resize_u8
     n = len(triplets)
     mine = shard_triplets(n, rank, world)
     ad = _Adapter(scorer)
@@ -169,7 +168,7 @@ def score_path_triplets(scorer, triplets: Sequence[Tuple[str, str, str, str]], i
     for j in mine:
         groups.setdefault(ad.group_key(triplets[j][3]), []).append(j)
     draws = None            # (eA, eB on the device; nA, nB): the same four tensors for every triplet (one reseeded generator)
-    pool = getattr(scorer, "_pool", None) or _shared_pool(world)
+    pool = getattr(scorer, "_decode", None) or _shared_pool()
     for key, idxs in groups.items():
         prompt = triplets[idxs[0]][3]
         ref, left, right = [], [], []
@@ -179,10 +178,10 @@ def score_path_triplets(scorer, triplets: Sequence[Tuple[str, str, str, str]], i
             chunks = [idxs[c0:c0 + batch_triplets] for c0 in range(0, len(idxs), batch_triplets)]
 
             def submit(chunk):
-                return [pool.submit(lambda p_=triplets[j][k]: resize_u8(load_image(p_), img_size)) for j in chunk for k in (0, 1, 2)]
+                return pool.submit([triplets[j][k] for j in chunk for k in (0, 1, 2)], img_size)
             pending = [submit(c) for c in chunks[:2]]                # decode runs two chunks ahead of the GPU
             for ci, chunk in enumerate(chunks):
-                px = torch.cat([f.result() for f in pending.pop(0)])
+                px = DecodePool.gather(pending.pop(0))
                 if ci + 2 < len(chunks):
                     pending.append(submit(chunks[ci + 2]))
                 x = image_preprocess(px.to(vae.device, non_blocking=True), ad.image_half)
@@ -240,12 +239,11 @@ def _prepare(scorer, ad: _Adapter, tensor, generator):
 _POOL = None
 
 
-def _shared_pool(world: int = 1):
-    """Decode / resize threads for scorers that own none: the host's cores divided among the ranks of this node."""
+def _shared_pool():
+    """Decode pool for scorers that own none (diffsim_xl, diffsim_DiT): the host's cores divided among the node's ranks."""
     global _POOL
     if _POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _POOL = ThreadPoolExecutor(max_workers=host_threads(world))
+        _POOL = DecodePool()
     return _POOL
 
 

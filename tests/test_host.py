@@ -187,3 +187,27 @@ def test_loader_reads_sharded_checkpoints_and_refuses_ambiguity(tmp_path):
     with pytest.raises(ValueError, match="bf16 or fp32"):
         loader._torch_dtype("fp16")
     assert loader._json(str(tmp_path / "nowhere")) == {}
+
+
+def test_decode_pool_processes_match_the_in_process_path(tmp_path):
+    """image.DecodePool: worker processes (pipes, PIL + numpy only) return exactly resize_u8's pixels, in order, for threads
+    and for processes; a bad path raises in the caller with the worker's message."""
+    from PIL import Image
+    from diffsim_amd.image import DecodePool, load_image, resize_u8
+    rng = np.random.default_rng(0)
+    paths = []
+    for i in range(5):
+        p = str(tmp_path / f"im{i}.png")
+        Image.fromarray(rng.integers(0, 255, (40 + i, 50, 3), dtype=np.uint8)).save(p)
+        paths.append(p)
+    want = torch.cat([resize_u8(load_image(p), 32) for p in paths])
+    for procs in (0, 2):
+        pool = DecodePool(procs=procs, threads=2)
+        got = DecodePool.gather(pool.submit(paths, 32))
+        assert got.dtype == torch.uint8 and torch.equal(got, want)
+        assert torch.equal(DecodePool.gather(pool.submit(paths[::-1], 32)), want.flip(0))
+        if procs:
+            with pytest.raises(RuntimeError, match="decode worker failed"):
+                DecodePool.gather(pool.submit([str(tmp_path / "missing.png")], 32))
+            assert torch.equal(DecodePool.gather(pool.submit(paths[:2], 32)), want[:2])       # the workers survive a failure
+        pool.shutdown()

@@ -55,6 +55,8 @@ def rocprof_name(fam: str) -> str:
         if p[1] == "fp8":
             return f"attn_fp8_kernel<{p[2][1:]}>"
         return f"attn_kernel<{'__bf16' if p[1] == 'bf16' else 'float'}, {p[2][1:]}>"
+    if p[0] == "ff":
+        return "ff_fused_kernel<0>"
     return fam           # groupnorm / layernorm families span several kernel symbols
 
 
@@ -155,6 +157,15 @@ def roofline_fields(recs, peak, tail=None, dump=None):
                 "avg_launch_ms": round(ms / n, 4), "algorithmic_mb_per_launch": round(by / n / 1e6, 1)}
 
     order = sorted(fam, key=lambda n_: -fam[n_][3])
+    # The dominant kernel symbol by time.  When the runner-up is within 5 % (the 3x3-conv GEMM and the 64x64 self-attention
+    # have been that close: which one led changed from run to run), the choice is made by NAME instead -- MFMA GEMM symbols
+    # first, then alphabetically -- so that the same build always reports the same kernel; the other one is always in
+    # roofline_top_kernels[0].
+    if len(order) > 1 and fam[order[1]][3] >= 0.95 * fam[order[0]][3]:
+        close = [n_ for n_ in order if fam[n_][3] >= 0.95 * fam[order[0]][3]]
+        first = sorted(close, key=lambda n_: (not n_.startswith("gemm_"), n_))[0]
+        order.remove(first)
+        order.insert(0, first)
     dom = entry(order[0])
     dom["traffic"] = pmc_traffic(dom["kernel"])
     out = {"roofline": dom, "roofline_top_kernels": [entry(n_) for n_ in order[1:7]],

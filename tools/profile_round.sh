@@ -24,13 +24,27 @@ for t in tap1 tap2; do find $R/gpurun_out/prof_${TAG}_$t -type f ! -name "*count
 # kernel stats of the secondary configs
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_trace_sdxl -- python3 $R/bench.py --model sdxl --batch-pairs 8 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/rocprof_${TAG}_trace_sdxl.log; echo trace_sdxl rc=$?
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_trace_pixels -- python3 $R/bench.py --pixels-in --batch-pairs 16 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/rocprof_${TAG}_trace_pixels.log; echo trace_pixels rc=$?
-for t in trace_sdxl trace_pixels; do find $R/gpurun_out/prof_${TAG}_$t -type f ! -name "*kernel_stats.csv" -delete; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_trace_dit -- python3 $R/bench.py --model dit --batch-pairs 64 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/rocprof_${TAG}_trace_dit.log; echo trace_dit rc=$?
+for t in trace_sdxl trace_pixels trace_dit; do find $R/gpurun_out/prof_${TAG}_$t -type f ! -name "*kernel_stats.csv" -delete; done
+# PMC passes of the secondary models (their roofline.traffic / mfma_util_pmc fields): --pmc only, one counter set per run
+for m in dit sdxl; do
+  bpm=64; [ $m = sdxl ] && bpm=8
+  for c in fetch:FETCH_SIZE write:WRITE_SIZE "mfma:SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    name=${c%%:*}; ctr=${c#*:}
+    rocprofv3 --pmc $ctr --output-format csv -d $R/gpurun_out/prof_${TAG}_${m}_${name} -- python3 $R/bench.py --model $m --batch-pairs $bpm --steps 1 --warmup 0 --no-cpu-baseline --no-profile > /dev/null 2> $R/gpurun_out/rocprof_${TAG}_${m}_${name}.log
+    echo ${m}_$name rc=$?
+    find $R/gpurun_out/prof_${TAG}_${m}_${name} -type f ! -name "*counter_collection.csv" -delete
+  done
+done
 cd $R
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.log; echo bench rc=$?
 python3 bench.py --steps 20 --warmup 5 --streams 2 --no-cpu-baseline > gpurun_out/bench_${TAG}_two_streams.json 2> gpurun_out/bench_${TAG}_two_streams.log; echo two_streams rc=$?
-python3 bench.py --model sdxl --batch-pairs 8 --steps 6 --warmup 2 > gpurun_out/bench_${TAG}_sdxl.json 2> gpurun_out/bench_${TAG}_sdxl.log; echo sdxl rc=$?
-python3 bench.py --model dit --batch-pairs 64 --steps 10 --warmup 3 > gpurun_out/bench_${TAG}_dit.json 2> gpurun_out/bench_${TAG}_dit.log; echo dit rc=$?
-python3 bench.py --model dit --fp8-attention --batch-pairs 64 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_${TAG}_dit_fp8.json 2> gpurun_out/bench_${TAG}_dit_fp8.log; echo ditfp8 rc=$?
-python3 bench.py --pixels-in --batch-pairs 16 --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/bench_${TAG}_pixels_in.json 2> gpurun_out/bench_${TAG}_pixels_in.log; echo pixels rc=$?
-python3 tools/files_in_bench.py > gpurun_out/bench_${TAG}_files_in.json 2> gpurun_out/bench_${TAG}_files_in.log; echo files_in rc=$?
+python3 bench.py --model sdxl --steps 6 --warmup 2 > gpurun_out/bench_${TAG}_sdxl.json 2> gpurun_out/bench_${TAG}_sdxl.log; echo sdxl rc=$?
+python3 bench.py --model dit --steps 10 --warmup 3 > gpurun_out/bench_${TAG}_dit.json 2> gpurun_out/bench_${TAG}_dit.log; echo dit rc=$?
+python3 bench.py --model dit --fp8-attention --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_${TAG}_dit_fp8.json 2> gpurun_out/bench_${TAG}_dit_fp8.log; echo ditfp8 rc=$?
+python3 bench.py --pixels-in --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/bench_${TAG}_pixels_in.json 2> gpurun_out/bench_${TAG}_pixels_in.log; echo pixels rc=$?
+python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --fusion 0 > gpurun_out/bench_${TAG}_unfused.json 2> gpurun_out/bench_${TAG}_unfused.log; echo unfused rc=$?
+python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --dedup-cfg > gpurun_out/bench_${TAG}_dedup_cfg.json 2> gpurun_out/bench_${TAG}_dedup_cfg.log; echo dedup rc=$?
+python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --dump-launches gpurun_out/launches_${TAG}.jsonl > /dev/null 2>&1; echo launches rc=$?
+DSIM_DECODE_PROCS=auto python3 tools/files_in_bench.py > gpurun_out/bench_${TAG}_files_in.json 2> gpurun_out/bench_${TAG}_files_in.log; echo files_in rc=$?
 tail -c 400 gpurun_out/bench_${TAG}.json

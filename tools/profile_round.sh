@@ -43,7 +43,7 @@ python3 bench.py --model sdxl --steps 6 --warmup 2 > gpurun_out/bench_${TAG}_sdx
 python3 bench.py --model dit --steps 10 --warmup 3 > gpurun_out/bench_${TAG}_dit.json 2> gpurun_out/bench_${TAG}_dit.log; echo dit rc=$?
 python3 bench.py --model dit --fp8-attention --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_${TAG}_dit_fp8.json 2> gpurun_out/bench_${TAG}_dit_fp8.log; echo ditfp8 rc=$?
 python3 bench.py --pixels-in --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/bench_${TAG}_pixels_in.json 2> gpurun_out/bench_${TAG}_pixels_in.log; echo pixels rc=$?
-python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --fusion 0 > gpurun_out/bench_${TAG}_unfused.json 2> gpurun_out/bench_${TAG}_unfused.log; echo unfused rc=$?
+python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --fusion 0 --batch-pairs 32 > gpurun_out/bench_${TAG}_unfused.json 2> gpurun_out/bench_${TAG}_unfused.log; echo unfused rc=$?
 python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --dedup-cfg > gpurun_out/bench_${TAG}_dedup_cfg.json 2> gpurun_out/bench_${TAG}_dedup_cfg.log; echo dedup rc=$?
 python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --dump-launches gpurun_out/launches_${TAG}.jsonl > /dev/null 2>&1; echo launches rc=$?
 DSIM_DECODE_PROCS=auto python3 tools/files_in_bench.py > gpurun_out/bench_${TAG}_files_in.json 2> gpurun_out/bench_${TAG}_files_in.log; echo files_in rc=$?

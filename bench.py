@@ -54,7 +54,7 @@ def rocprof_name(fam: str) -> str:
     if p[0] == "attention":
         if p[1] == "fp8":
             return f"attn_fp8_kernel<{p[2][1:]}>"
-        return f"attn_kernel<{'__bf16' if p[1] == 'bf16' else 'float'}, {p[2][1:]}>"
+        return f"attn_kernel<{'__bf16' if p[1] == 'bf16' else 'float'}, {p[2][1:]}, {'true' if fam.endswith('_long') else 'false'}>"
     if p[0] == "ff":
         return "ff_fused_kernel<0>"
     return fam           # groupnorm / layernorm families span several kernel symbols

@@ -199,9 +199,14 @@ __device__ __forceinline__ void tile_store(char* lds, const StageRegs<T, D>& sr,
 // One full attention of this wave's 32 query rows against Nk keys.  On return o[db][r] holds the
 // NORMALISED output O^T[d = db*32 + (r&3)+8(r>>2)+4*half][q = lane&31].  All 256 threads of the
 // workgroup must call it together (it contains workgroup barriers).
-template <typename T, int D>
+// FAST: the running maximum is fixed after key tile 0 -- the later tiles compute P = exp2(S - m) without looking at their
+// scores at all (no row maximum, no re-base test, no rescale: a third of the loop's non-exp vector instructions).  Softmax is
+// invariant to the reference point, so a row whose true maximum lies above m just carries P > 1 and larger sums (f32 / bf16
+// have the exponent range for it).  Only if the excess passes ~100 (log2 units) can exp2 overflow; the caller detects that from a
+// non-finite or absurd denominator and re-runs the block with FAST = false (attend_checked).
+template <typename T, int D, bool FAST = false>
 __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, const T* vb, int ldk, int Nk, char* lds,
-                                       OAcc<T, D>& oacc) {
+                                       OAcc<T, D>& oacc, float* l_out = nullptr) {
     typedef ACfg<T, D> C;
     typedef typename FragOf<T>::type Frag;
     QFrags<T, D> qloc = qfr;    // (KONE writes -m into the spare d = D slot of its own copy)
@@ -213,6 +218,9 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
     float m_run = 0.f;          // running row max (log2 units); meaningful after tile 0 (KONE: a bf16 value)
+    f32x16 minit;               // the S^T accumulators' start value: -m_run (KONE: 0, the maximum rides in Q's spare slot)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) minit[r] = 0.f;
     float l_run = 0.f;          // used only when !ONES
 
     const int ntiles = (Nk + KT - 1) / KT;
@@ -238,11 +246,9 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
 
         // ---- S'^T = K Q^T - m for the two 32-row kv blocks (accumulators start at -m) ----------
         f32x16 s[2];
-        const float cinit = C::KONE ? 0.f : -m_run;
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[jb][r] = cinit;
+            s[jb] = minit;                  // -m in every register (KONE: the constant 0): the first MFMA reads it as its C operand
             const char* krow = lds + (jb * 32 + l31) * C::RS + half * 8 * C::ES;
 #pragma unroll
             for (int ks = 0; ks < C::NKS; ++ks) {
@@ -262,17 +268,19 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
         }
         // ---- online softmax (per query column == per lane) ---------------------------------
         float tmax = -INFINITY;
+        if (!FAST || kt == 0) {
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
+            for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[jb][r]);
-        tmax = max_halves(tmax);
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[jb][r]);
+            tmax = max_halves(tmax);
+        }
         // tmax is relative to m_run.  Tile 0 always re-bases; later tiles only when some row's max
         // grew (the running max settles after a few tiles) -- exact, not a threshold.
         // (KONE re-bases only past a slack of 0.5, so that rounding m to bf16 cannot leave a row just above 0 and
         // re-trigger on every tile; P <= 1.42 there)
         constexpr float SLACK = C::KONE ? 0.5f : 0.f;
-        if (kt == 0 || !__all(tmax <= SLACK)) {
+        if (kt == 0 || (!FAST && !__all(tmax <= SLACK))) {
             float delta = kt == 0 ? tmax : fmaxf(tmax, 0.f);
             if constexpr (C::KONE) {
                 if constexpr (sizeof(T) == 2) {
@@ -283,6 +291,8 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
                 }
             } else {
                 m_run += delta;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) minit[r] = -m_run;
             }
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb)
@@ -365,6 +375,7 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
     } else {
         l_tot = l_run + __shfl_xor(l_run, 32);
     }
+    if (l_out) *l_out = l_tot;
     const float inv = 1.0f / l_tot;
 #pragma unroll
     for (int db = 0; db < C::NDB; ++db)
@@ -372,8 +383,26 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
         for (int r = 0; r < 16; ++r) o[db][r] *= inv;
 }
 
+// The fast form, checked: every row's denominator must be finite and sane (it is >= ~1 by construction: the row's own
+// tile-0 maximum contributes exp2(0)); otherwise some exp2 overflowed and the whole workgroup repeats the block exactly.
+// bf16 only (the fp32 parity mode keeps the exact running maximum).
+template <typename T, int D, bool FASTK>
+__device__ __forceinline__ void attend_checked(const QFrags<T, D>& qfr, const T* kb, const T* vb, int ldk, int Nk, char* lds,
+                                               OAcc<T, D>& oacc) {
+    if constexpr (sizeof(T) == 2 && FASTK) {
+        float l = 0.f;
+        attend<T, D, true>(qfr, kb, vb, ldk, Nk, lds, oacc, &l);
+        // workgroup-uniform decision (attend() contains workgroup barriers): any wave with a bad row sends everybody back
+        const int bad = !(l > 0.25f && l < 1e30f);
+        if (__syncthreads_or(bad)) attend<T, D, false>(qfr, kb, vb, ldk, Nk, lds, oacc);
+    } else {
+        attend<T, D, false>(qfr, kb, vb, ldk, Nk, lds, oacc);
+    }
+}
+
 // grid ceil(Nq/128) * H * B (1-D)
-template <typename T, int D>
+// FASTK: the fixed-reference softmax of attend<.., FAST> (long key sequences; see launch_attn_d)
+template <typename T, int D, bool FASTK>
 __global__ __launch_bounds__(256, (ACfg<T, D>::WPS)) void attn_kernel(const AttnArgs p, const float scale_log2) {
     typedef ACfg<T, D> C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -396,7 +425,7 @@ __global__ __launch_bounds__(256, (ACfg<T, D>::WPS)) void attn_kernel(const Attn
     load_q<T, D>(qf, qrow, half, scale_log2);
     const size_t kvoff = (size_t)(b % p.Bkv) * p.Nk * p.ldk + h * D;
     OAcc<T, D> oa;
-    attend<T, D>(qf, (const T*)p.k + kvoff, (const T*)p.v + kvoff, p.ldk, p.Nk, smem, oa);
+    attend_checked<T, D, FASTK>(qf, (const T*)p.k + kvoff, (const T*)p.v + kvoff, p.ldk, p.Nk, smem, oa);
     auto& o = oa.b;
     if (q < p.Nq) {
         T* orow = (T*)p.out + ((size_t)b * p.Nq + q) * p.ldo + h * D;
@@ -509,10 +538,21 @@ inline float scale_log2_of(int D) { return (1.0f / sqrtf((float)D)) * 1.44269504
 template <typename T, int D>
 int launch_attn_d(const AttnArgs& a, hipStream_t s) {
     typedef ACfg<T, D> C;
-    static DeviceOnce once;
-    auto kern = attn_kernel<T, D>;
-    CK_ONCE(once, kern, C::LDS);
-    hipLaunchKernelGGL(kern, dim3(((a.Nq + 127) / 128) * a.H * a.B), dim3(256), C::LDS, s, a, scale_log2_of(D));
+    const dim3 grid(((a.Nq + 127) / 128) * a.H * a.B);
+    // long key sequences (the 64 x 64 self-attention: 64 key tiles per block): the fixed-reference softmax, 6 % faster at
+    // 4096 keys x d = 40; short ones (cross-attention's 77 keys, the 16 x 16 level) keep the exact running maximum -- there the
+    // end-of-block check costs more than the skipped maxima save
+    if (sizeof(T) == 2 && a.Nk >= 2048) {
+        static DeviceOnce oncef;
+        auto kern = attn_kernel<T, D, true>;
+        CK_ONCE(oncef, kern, C::LDS);
+        hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS, s, a, scale_log2_of(D));
+    } else {
+        static DeviceOnce once;
+        auto kern = attn_kernel<T, D, false>;
+        CK_ONCE(once, kern, C::LDS);
+        hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS, s, a, scale_log2_of(D));
+    }
     DSIM_HIP_CHECK(hipGetLastError());
     return DSIM_OK;
 }

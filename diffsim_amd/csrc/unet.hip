@@ -142,7 +142,9 @@ struct Walk {
     }
     int attn(const AttnArgs& a) {
         if (!run) return DSIM_OK;
-        pbegin(std::string("attention_") + dtn() + "_d" + std::to_string(a.D) + "|B" + std::to_string(a.B) + " H" + std::to_string(a.H) +
+        // (key sequences >= 2048 run the fixed-reference instantiation attn_kernel<T, D, true>: its own family)
+        pbegin(std::string("attention_") + dtn() + "_d" + std::to_string(a.D) + (a.Nk >= 2048 && h->dt == DSIM_BF16 ? "_long" : "") +
+                   "|B" + std::to_string(a.B) + " H" + std::to_string(a.H) +
                    " Nq" + std::to_string(a.Nq) + " Nk" + std::to_string(a.Nk),
                4.0 * a.B * a.H * (double)a.Nq * a.Nk * a.D,
                (double)es() * a.B * a.H * a.D * (2.0 * a.Nq + 2.0 * a.Nk));

@@ -409,3 +409,36 @@ def test_ff_fused_320(eng, M):
     eng._lib.check(L.dsim_op_ff_fused(x2.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ws[3].data_ptr(),
                                       ws[4].data_ptr(), ws[5].data_ptr(), x2.data_ptr(), M, C, 1e-5, None), "ff in place")
     assert torch.equal(x2, got)
+
+
+@pytest.mark.parametrize("D", [40, 64, 80])
+def test_attention_long_keys_fixed_reference_softmax(eng, D):
+    """Key sequences >= 2048 take the fixed-reference softmax (the maximum is fixed after key tile 0, later tiles never look
+    at their scores; attention.hip attend<FAST>).  (1) ordinary data; (2) the rare branch, FORCED (cdna_hip_programming.md rule
+    26): one key far down the sequence scores ~+40 (log2 units) above everything in tile 0 for some rows -> P up to 2^40,
+    still exact after normalisation; (3) a key ~+300 above -> exp2 overflows in the fast form, the end-of-block check must
+    send the workgroup through the exact running-maximum form.  All against float64 SDPA over the whole tensor."""
+    dtype = torch.bfloat16
+    B, H, Nq, Nk = 1, 2, 256, 2048 + 77
+    g = torch.Generator().manual_seed(D)
+    q = torch.randn(B, Nq, H * D, generator=g)
+    k = torch.randn(B, Nk, H * D, generator=g)
+    v = torch.randn(B, Nk, H * D, generator=g)
+    for case, boost in (("plain", 0.0), ("late spike", 28.0), ("overflow", 210.0)):
+        kk = k.clone()
+        if boost:       # key 1500 of head 0 aligned with query row 7 of head 0: its logit is `boost` (natural units) exactly
+            q7 = q[0, 7, :D]
+            kk[0, 1500, :D] = boost * q7 / (q7.norm() ** 2) * math.sqrt(D)
+        qh, kh, vh = (_q(t, dtype) for t in (q, kk, v))
+        want = F.scaled_dot_product_attention(qh.double().view(B, Nq, H, D).transpose(1, 2), kh.double().view(B, Nk, H, D).transpose(1, 2),
+                                              vh.double().view(B, Nk, H, D).transpose(1, 2)).transpose(1, 2).reshape(B, Nq, H * D).float()
+        got = eng.op_attention(_dev(q, dtype), _dev(kk, dtype), _dev(v, dtype), H)
+        assert torch.isfinite(got.float()).all(), case
+        if case == "overflow":
+            # logits in the hundreds: the documented drift of near-tie rows under the bf16 pre-scaled Q (test_attention_peaked_logits)
+            # applies to the exact form too; here the point is that the fallback ran: finite, and within 5 % of the range
+            assert (got.float().cpu() - want).abs().max().item() <= 5e-2 * float(want.abs().max())
+        else:
+            _close(got, want, dtype)
+        if boost:                   # the spiked row is one-hot on key 1500
+            assert (got[0, 7, :D].float().cpu() - vh[0, 1500, :D]).abs().max().item() < 2e-2, case

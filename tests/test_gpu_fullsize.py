@@ -55,10 +55,12 @@ def test_sdxl_1024px_two_taps():
     """Config 4: the SDXL U-Net at 1024 px (128 x 128 latents), taps up_blocks [0,0,0] and [0,1,9] (the last block of
     a depth-10 transformer; diffsim/diffsim_xl.py:88-107), both from one shared weight copy.
 
-    The oracle is evaluated in FLOAT64 here.  34 transformer blocks of random weights sit in front of these taps and
-    torch's fp32 CPU kernels are themselves 1.0e-4 (relative, on the score) away from the float64 evaluation of the same
-    graph, while the HIP fp32 mode is 2e-8 / 5e-8 away (tests/probe_sdxl_f64.py, profiles/r02_sdxl_f64_probe.txt): against
-    the fp32 CPU numbers the 1e-4 gate would measure the CPU library's rounding, not the kernels'."""
+    The oracle's U-Net runs in fp32 (the north_star's "reference CPU path in fp32"); only the LAST op of its score tail,
+    F.cosine_similarity over 2.6 M elements (diffsim/diffsim.py:187-190), is evaluated in float64.  That one op is the whole
+    1.0e-4 distance between the fp32 CPU oracle and the float64 evaluation of this graph (tests/probe_sdxl_f32_ops.py ->
+    profiles/r03_sdxl_f32_ops_probe.txt: fp32 features + float64 cosine are 1.5e-8 from float64; with torch's fp32 CPU
+    reduction 1.03e-4) -- against the all-fp32 tail the 1e-4 gate would measure that reduction's rounding, not the kernels'.
+    (The HIP tail folds its partial sums in float64 in a fixed order; the all-fp32 CPU score is asserted to stay within 3e-4.)"""
     from oracle import cpu_ref as R
     from diffsim_amd.diffsim_xl import diffsim_xl
     cfg = C.SDXL
@@ -67,7 +69,7 @@ def test_sdxl_1024px_two_taps():
     shapes = C.unet_param_shapes(cfg)
     sd = S.make_state_dict(cfg, seed=0, keys=[k for k in shapes if not k.startswith(drop)])
     f64 = torch.float64
-    unet = _oracle_unet(R, R.SDXL, sd, shapes, f64)
+    unet = _oracle_unet(R, R.SDXL, sd, shapes, torch.float32)
     ctx, pooled = S.make_context(cfg), S.make_pooled(cfg)
     g = torch.Generator("cpu").manual_seed(1234)
     shp = (1, 4, 128, 128)
@@ -77,14 +79,16 @@ def test_sdxl_1024px_two_taps():
     feats = []
     for z, nz in ((zA, n[2]), (zB, n[3])):
         x, t = R.sdxl_inputs(z, nz, 600)
-        added = {"text_embeds": pooled.to(f64), "time_ids": R.sdxl_time_ids(unet.cfg).repeat(2, 1).to(f64)}
-        feats.append(_qkv_at_taps(R, unet, torch.cat([x] * 2).to(f64), t, ctx.to(f64), added, taps))
-    want = {name: float(R.pair_score(*feats[0][name], *feats[1][name], "cosine")) for name in taps}
+        added = {"text_embeds": pooled, "time_ids": R.sdxl_time_ids(unet.cfg).repeat(2, 1)}
+        feats.append(_qkv_at_taps(R, unet, torch.cat([x] * 2), t, ctx, added, taps))
+    want = {name: float(R.pair_score(*[f.to(f64) for f in feats[0][name]], *[f.to(f64) for f in feats[1][name]], "cosine")) for name in taps}
+    want32 = {name: float(R.pair_score(*feats[0][name], *feats[1][name], "cosine")) for name in taps}
     del unet
     xl = diffsim_xl(torch.float32, "cuda", unet_config=cfg, state_dict=sd)
     for name, (blk, tl) in taps.items():
         s = float(xl.score_latent_pairs(zA, zB, n[2], n[3], ctx, pooled, blk, tl, 600, "cosine").cpu())
         assert _rel(s, want[name]) <= REL_F32, (name, s, want[name])
+        assert _rel(s, want32[name]) <= 3e-4, (name, s, want32[name])       # the all-fp32 CPU tail: its own reduction error
     assert xl._base is not None and len(xl._engines) == 2          # two taps, ONE packed weight copy
     q, k, v = xl.features(zB, n[3], ctx, pooled, "up_blocks", [0, 0, 0], 600)
     for got, ref in zip((q, k, v), feats[1]["a"]):

@@ -125,7 +125,7 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.dsim_version() != 4:
+        if L.dsim_version() != 5:
             raise DsimError("ABI version mismatch")
         _lib = L
     return _lib

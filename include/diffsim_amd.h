@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DSIM_ABI_VERSION 4
+#define DSIM_ABI_VERSION 5
 
 typedef enum dsim_status {
     DSIM_OK = 0,

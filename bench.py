@@ -57,6 +57,8 @@ def rocprof_name(fam: str) -> str:
         return f"attn_kernel<{'__bf16' if p[1] == 'bf16' else 'float'}, {p[2][1:]}, {'true' if fam.endswith('_long') else 'false'}>"
     if p[0] == "ff":
         return "ff_fused_kernel<0>"
+    if p[0] == "ln" and p[1] == "linear":
+        return "rowlin_kernel<0>"
     return fam           # groupnorm / layernorm families span several kernel symbols
 
 

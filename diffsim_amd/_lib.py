@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(HERE, "libdiffsim_amd.so")
 DSIM_F32, DSIM_BF16, DSIM_F16 = 0, 1, 2
 TAP = {"down_blocks": 0, "mid_blocks": 1, "up_blocks": 2}
 MAX_LEVELS = 4
-FUSE_FF, FUSE_ALL = 1, 1        # dsim_unet_set_fusion bits
+FUSE_FF, FUSE_LNPROJ, FUSE_ALL = 1, 2, 3        # dsim_unet_set_fusion bits
 
 
 class DsimError(RuntimeError):
@@ -107,6 +107,7 @@ SYMBOLS = {
     "dsim_op_attention": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsim_op_attention_fp8": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "dsim_op_ff_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "dsim_op_ln_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
 }
 
 _lib = None
@@ -125,7 +126,7 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.dsim_version() != 5:
+        if L.dsim_version() != 6:
             raise DsimError("ABI version mismatch")
         _lib = L
     return _lib

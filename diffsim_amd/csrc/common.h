@@ -73,6 +73,7 @@ extern int g_gn_onepass;        // DSIM_GN_ONEPASS
 extern int g_ln_rows;           // DSIM_LN_ROWS
 extern int g_prep8;             // DSIM_PREP8
 extern int g_ff_dbg;            // ablation mask of the fused feed-forward kernel (rowres.hip)
+extern int g_rl_dbg;            // ablation mask of the row-resident Linear kernel (rowres.hip)
 extern int g_ff_stagger;        // its wave de-phasing, in s_nop 7 units per wave index
 #else
 constexpr int g_gemm_persistent = 1, g_force_bm = 0, g_gn_onepass = 1, g_ln_rows = 1, g_prep8 = 1;
@@ -102,6 +103,20 @@ int prep_conv_in(const float* lat, const float* noise /*nullable*/, float sa, fl
 int convert_f32_to(const float* src, void* dst, int dtype, size_t n, hipStream_t s);
 // out[2b], out[2b+1] = in[b]: a batch element becomes its two classifier-free-guidance copies (bytes_per_elem % 16 == 0)
 int dup_batch(const void* in, void* out, int n_batch, size_t bytes_per_elem, hipStream_t s);
+
+// row-resident Linear for K = 320 (optionally behind a LayerNorm): out[M][N] = LN?(x) W^T (+ bias), N % 64 == 0, N <= 960 -- rowres.hip
+struct RowLinArgs {
+    const void* x = nullptr;                    // [M][C] bf16
+    void* out = nullptr;                        // [M][N] bf16
+    const float* ln_g = nullptr;                // null: no LayerNorm in front
+    const float* ln_b = nullptr;
+    const void* stream = nullptr;               // pack_rowlin_stream output
+    int M = 0, C = 0, N = 0;
+    float eps = 1e-5f;
+};
+size_t rowlin_stream_bytes(int C, int N);       // 0: shape not covered
+int pack_rowlin_stream(const void* w_packed /*[N][C] bf16*/, void* stream, int C, int N, hipStream_t s);
+int launch_rowlin(const RowLinArgs& a, hipStream_t s);
 
 // uint8 HWC pixels -> process_image's normalised NCHW f32 (half: rounded through fp16); VAE posterior sample -- pack.hip
 int image_preprocess(const unsigned char* hwc, float* out, int n, int H, int W, int half, hipStream_t s);

@@ -359,9 +359,200 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FFParams p, cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---- row-resident Linear (optionally behind a LayerNorm) for K = 320 -----------------------------------------------------
+// out[M][N] = LN?(x)[M][320] W^T (+ bias), N a multiple of 64: the fused to_q/to_k/to_v projection behind norm1 (N = 960) and
+// attn2.to_q behind norm2 (hacked_modules.py:88-116).  The tiled GEMM is latency-bound on these: a K of five tiles leaves its
+// two-stage ring one 1.2 us K step of cover for activations that stream from HBM exactly once (726 TF/s, 3.0 TB/s at N = 960),
+// and the LayerNorm in front costs a full read + write of the tensor.  Here a wave keeps its 32 rows in registers
+// (normalised on arrival), the weights stream through a 2-slot LDS ring in 32-column blocks, the output leaves in
+// 128-byte row segments per pair of blocks -- HBM-bound, one pass.  Two 4-wave workgroups per CU (<= 256 registers, 66 KB
+// of LDS): one workgroup's row loads and stores sit under the other's MFMAs.
+constexpr int LCHB = 32 * RC * 2;              // 20480 bytes per ring slot: W rows [32 b, 32 b + 32) x K 320, five [32][128 B] slabs
+constexpr int LPW = LCHB / 1024 / 4;           // 5 DMA pieces per wave per block
+constexpr int LVEC = 2 * RC;                   // resident f32: LayerNorm gamma, beta
+constexpr int LSCR = 16 * 144;                 // per-wave transpose slab: 16 rows x (64 cols bf16 + 16 pad)
+constexpr int LLDS = 2 * LCHB + LVEC * 4 + 4 * LSCR;      // 52736: three workgroups per CU
+
+__global__ void pack_rowlin_stream_kernel(const bf16* __restrict__ wp, char* __restrict__ stream, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N / 32 * (LCHB / 16)) return;
+    const int b = i / (LCHB / 16), o = (i - b * (LCHB / 16)) * 16;
+    const int slab = o / 4096, row = (o % 4096) / 128, cpos = (o % 128) / 16;
+    const int cl = cpos ^ ((row >> 1) & 7);
+    *reinterpret_cast<u32x4*>(stream + (size_t)b * LCHB + o) =
+        *reinterpret_cast<const u32x4*>(wp + (size_t)(32 * b + row) * RC + 64 * slab + 8 * cl);
+}
+
+struct RLParams {
+    const bf16* x;
+    bf16* out;
+    const float* ln_g;      // null: no LayerNorm
+    const float* ln_b;
+    const char* stream;
+    int M, N;
+    float eps;
+    unsigned x_bytes, out_bytes, stream_bytes;
+};
+
+template <int DBG>      // DBG: kbench ablation masks (1 no output stores, 2 no MFMAs, 4 no row loads, 8 no fragment reads); 0 in the product
+__global__ __launch_bounds__(256, 3) void rowlin_kernel(const RLParams p, const int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)p.stream, 0, (int)p.stream_bytes, 0x00020000);
+    const int nblk = p.N / 32;                 // even
+    auto dma = [&](int sp, int blk) {           // this wave's five pieces of weight block `blk` into the slot of parity sp
+        char* dst = smem + sp * LCHB + wave * (LPW * 1024);
+#pragma unroll
+        for (int d = 0; d < LPW; ++d)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rS, (__attribute__((address_space(3))) void*)(dst + d * 1024), 16, lane * 16,
+                                                     blk * LCHB + wave * (LPW * 1024) + d * 1024, 0, 0);
+    };
+    dma(0, 0);
+    float* const vec = reinterpret_cast<float*>(smem + 2 * LCHB);         // [gamma 320 | beta 320]
+    if (p.ln_g)
+        for (int i = tid; i < LVEC; i += 256) vec[i] = i < RC ? p.ln_g[i] : p.ln_b[i - RC];
+    char* const slab = smem + 2 * LCHB + LVEC * 4 + wave * LSCR;
+    const int sw1 = (l31 >> 1) & 7;
+    int woff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) woff[kk] = l31 * 128 + (((2 * kk + half) ^ sw1) << 4);
+    __syncthreads();
+    int blk = 0;                                // weight block the NEXT ring step consumes (wraps at nblk: same weights for every tile)
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m0 = tile * 128 + wave * 32;
+        // the rows live in ONE register array: raw bf16 on arrival, overwritten in place by their normalised values
+        u32x4 xr[RKS];
+        {
+            const int row = m0 + l31;
+            const unsigned rbase = row < p.M ? (unsigned)row * (RC * 2) + half * 16 : OOB;
+#pragma unroll
+            for (int ks = 0; ks < RKS; ++ks)
+                xr[ks] = (DBG & 4) ? u32x4{(unsigned)ks, 1u, 2u, rbase} : __builtin_amdgcn_raw_buffer_load_b128(rX, (int)(rbase + ks * 32), 0, 0);
+            if (p.ln_g) {                       // the LayerNorm of ff_fused_kernel (three passes over the bf16 registers)
+                float sum = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < RKS; ++ks) {
+                    const bf16x8 t = __builtin_bit_cast(bf16x8, xr[ks]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sum += (float)t[j];
+                }
+                {
+                    const unsigned u = __float_as_uint(sum);
+                    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                    sum = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                }
+                const float mean = sum * (1.0f / RC);
+                float sq = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < RKS; ++ks) {
+                    asm volatile("" : "+v"(xr[ks]));
+                    const bf16x8 t = __builtin_bit_cast(bf16x8, xr[ks]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float d = (float)t[j] - mean; sq = fmaf(d, d, sq); }
+                }
+                {
+                    const unsigned u = __float_as_uint(sq);
+                    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                    sq = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                }
+                const float rstd = 1.0f / sqrtf(sq * (1.0f / RC) + p.eps);
+#pragma unroll
+                for (int ks = 0; ks < RKS; ++ks) {
+                    const int c = 16 * ks + 8 * half;
+                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(vec + c), g1 = *reinterpret_cast<const f32x4*>(vec + c + 4);
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(vec + RC + c), b1 = *reinterpret_cast<const f32x4*>(vec + RC + c + 4);
+                    asm volatile("" : "+v"(xr[ks]));
+                    const bf16x8 t = __builtin_bit_cast(bf16x8, xr[ks]);
+                    bf16x8 y;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        y[j] = (bf16)fmaf(((float)t[j] - mean) * rstd, g0[j], b0[j]);
+                        y[4 + j] = (bf16)fmaf(((float)t[4 + j] - mean) * rstd, g1[j], b1[j]);
+                    }
+                    xr[ks] = __builtin_bit_cast(u32x4, y);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // one ring step: the 20 MFMAs of weight block `blk` (32 output columns) into `a`, fragments double-buffered by 64-wide K slab
+        bf16x8 wf[2][2];
+        auto step = [&](int sp, f32x16& a) {
+            // the slot's five DMA pieces must have landed; the four row-segment stores of the previous pair were issued after the
+            // pieces of an even step (vmcnt retires in issue order on gfx9): leave them in flight there
+            if (sp == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int nb = blk + 1 == nblk ? 0 : blk + 1;
+            dma(sp ^ 1, nb);
+            blk = nb;
+            const char* slot = smem + sp * LCHB;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a[e] = 0.f;
+            auto ld = [&](int i, bf16x8 (&w)[2]) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int ks = 2 * i + u;
+                    w[u] = *reinterpret_cast<const bf16x8*>(slot + (ks >> 2) * 4096 + woff[ks & 3]);
+                }
+            };
+            ld(0, wf[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                if (i < 9 && !(DBG & 8)) ld(i + 1, wf[(i + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (!(DBG & 2)) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i & 1][u], __builtin_bit_cast(bf16x8, xr[2 * i + u]), a, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // a pair of blocks = 64 output columns = 128-byte row segments: D^T -> row-major through the wave's 16-row slab in two
+        // passes (rows 0-15, 16-31), 16-byte stores of full lines
+        auto store_pair = [&](const f32x16& a0, const f32x16& a1, int col0) {
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                asm volatile("" ::: "memory");       // pass 1 overwrites the slab pass 0 is read from
+                if ((l31 >> 4) == ph) {
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            bf16x4 pk;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pk[e] = (bf16)(bb ? a1[4 * q + e] : a0[4 * q + e]);
+                            *reinterpret_cast<u32x2*>(slab + (l31 & 15) * 144 + (bb * 32 + 8 * q + 4 * half) * 2) = __builtin_bit_cast(u32x2, pk);
+                        }
+                }
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int idx = lane + it * 64, r = idx >> 3, c = idx & 7, row = m0 + 16 * ph + r;
+                    const unsigned go = row < p.M ? ((unsigned)row * (unsigned)p.N + (unsigned)col0) * 2u + (unsigned)c * 16u : OOB;
+                    const u32x4 t = *reinterpret_cast<const u32x4*>(slab + r * 144 + c * 16);
+                    if (!(DBG & 1) || t[0] == 0x12345u) __builtin_amdgcn_raw_buffer_store_b128(t, rO, (int)go, 0, 0);
+                }
+            }
+        };
+        f32x16 a0, a1;
+        for (int pr = 0; pr < nblk / 2; ++pr) {
+            step(0, a0);
+            step(1, a1);
+            store_pair(a0, a1, 64 * pr);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
 
 #ifdef DSIM_DEVTOOLS
+int g_rl_dbg = 0;
 int g_ff_dbg = 0;
 int g_ff_stagger = -1;     // -1 = the product default
 #endif
@@ -405,6 +596,41 @@ int launch_ff_fused(const FFArgs& a, hipStream_t s) {
     auto kern = ff_fused_kernel<0>;
     CK_ONCE(once, kern, RLDS);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), RLDS, s, p, ntiles);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+
+size_t rowlin_stream_bytes(int C, int N) { return (C == RC && N % 64 == 0 && N <= 960) ? (size_t)N / 32 * LCHB : 0; }
+
+int pack_rowlin_stream(const void* w_packed, void* stream, int C, int N, hipStream_t s) {
+    if (!rowlin_stream_bytes(C, N)) return DSIM_ERR_INVALID;
+    const int n = N / 32 * (LCHB / 16);
+    hipLaunchKernelGGL(pack_rowlin_stream_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16*)w_packed, (char*)stream, N);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+
+int launch_rowlin(const RowLinArgs& a, hipStream_t s) {
+    if (!rowlin_stream_bytes(a.C, a.N) || a.M < 1 || (size_t)a.M * a.N * 2 >= 0x7fffffffull || !a.ln_g != !a.ln_b) return DSIM_ERR_INVALID;
+    RLParams p;
+    p.x = (const bf16*)a.x; p.out = (bf16*)a.out; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.stream = (const char*)a.stream;
+    p.M = a.M; p.N = a.N; p.eps = a.eps;
+    p.x_bytes = (unsigned)((size_t)a.M * RC * 2); p.out_bytes = (unsigned)((size_t)a.M * a.N * 2);
+    p.stream_bytes = (unsigned)rowlin_stream_bytes(a.C, a.N);
+    const int ntiles = (a.M + 127) / 128;
+    const int grid = ntiles < 3 * cu_count() ? ntiles : 3 * cu_count();
+#ifdef DSIM_DEVTOOLS
+    switch (g_rl_dbg) {
+#define X(d) case d: { static DeviceOnce o; auto k = rowlin_kernel<d>; CK_ONCE(o, k, LLDS); hipLaunchKernelGGL(k, dim3(grid), dim3(256), LLDS, s, p, ntiles); DSIM_HIP_CHECK(hipGetLastError()); return DSIM_OK; }
+        X(1) X(2) X(4) X(8) X(10) X(15)
+#undef X
+        default: break;
+    }
+#endif
+    static DeviceOnce once;
+    auto kern = rowlin_kernel<0>;
+    CK_ONCE(once, kern, LLDS);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LLDS, s, p, ntiles);
     DSIM_HIP_CHECK(hipGetLastError());
     return DSIM_OK;
 }

@@ -31,7 +31,7 @@ struct dsim_unet : WeightStore {
     float* tscratch = nullptr;      // time-embedding scratch
     bool two_temb = false;          // SDXL: the CFG halves carry different time embeddings
     bool cfg_dedup = false;         // opt-in: compute the part of the graph that is identical in both CFG halves once
-    int fusion = DSIM_FUSE_FF;      // dsim_unet_set_fusion mask: which multi-op kernels replace their unfused chains
+    int fusion = DSIM_FUSE_ALL;     // dsim_unet_set_fusion mask: which multi-op kernels replace their unfused chains
 };
 
 namespace {
@@ -228,7 +228,35 @@ struct Walk {
         const bool pre = half_in && blk == 0;            // still on the de-duplicated half batch
         const int Mx = pre ? Mh : M;
         void* hbx = pre ? hbh : hb;
-        CK(ln(hbx, l1w, l1b, nb, Mx, C));
+        // LayerNorm + projection as one row-resident launch where the width has one (bf16, C = 320; not the tapped block, whose
+        // q, k, v go to three tensors)
+        auto ln_proj = [&](const void* xin, const Packed* g, const Packed* be, const std::string& key, void* o, int Mr, int N) -> int {
+            const auto it = h->pk.find(key);
+            if (it == h->pk.end() || !(h->fusion & DSIM_FUSE_LNPROJ)) return 1;          // 1: run the unfused chain
+            if (run) {
+                RowLinArgs ra;
+                ra.x = xin; ra.out = o; ra.ln_g = (const float*)g->p; ra.ln_b = (const float*)be->p; ra.stream = it->second.p;
+                ra.M = Mr; ra.C = C; ra.N = N; ra.eps = 1e-5f;
+                pbegin(std::string("ln_linear_") + dtn() + "|M" + std::to_string(Mr) + " N" + std::to_string(N) + " K" + std::to_string(C),
+                       2.0 * Mr * (double)C * N, (double)Mr * (C + N) * es() + (double)C * N * es());
+                const int st = launch_rowlin(ra, s);
+                pend();
+                if (st != DSIM_OK) return st;
+            }
+            return DSIM_OK;
+        };
+        const bool tapped_here = blk == tap_blk;
+        int fq = 1;
+        if (!tapped_here && !big) {
+            // qkv [M][3C]; later the GEGLU output [M][4C] unless the feed-forward runs as one launch
+            const bool ff1 = h->pk.count(b + "ff.stream") && (h->fusion & DSIM_FUSE_FF);
+            big = alloc_act((size_t)M * (ff1 ? 3 : 4) * C);
+            ab = alloc_act((size_t)M * C);
+            kvb = alloc_act((size_t)2 * L * 2 * C);
+        }
+        if (!tapped_here) fq = ln_proj(hbx, l1w, l1b, b + "attn1.qkv.stream", big, Mx, 3 * C);
+        if (fq < 0) return fq;
+        if (fq > 0) CK(ln(hbx, l1w, l1b, nb, Mx, C));
         if (blk == tap_blk) {
             // hacked_attn.py:61-69: to_q / to_k / to_v, no bias; written [B][N][H*D]
             Packed wq = *qkv, wk = *qkv, wv = *qkv;
@@ -249,14 +277,7 @@ struct Walk {
         WGET(f1w, b + "ff.net.0.proj.weight"); WGET(f1b, b + "ff.net.0.proj.bias");
         WGET(f2w, b + "ff.net.2.weight"); WGET(f2b, b + "ff.net.2.bias");
         // self-attention
-        if (!big) {
-            // qkv [M][3C]; later the GEGLU output [M][4C] unless the feed-forward runs as one launch
-            const bool ff1 = h->pk.count(b + "ff.stream") && (h->fusion & DSIM_FUSE_FF);
-            big = alloc_act((size_t)M * (ff1 ? 3 : 4) * C);
-            ab = alloc_act((size_t)M * C);
-            kvb = alloc_act((size_t)2 * L * 2 * C);
-        }
-        CK(linear(nb, C, nullptr, 0, qkv, nullptr, nullptr, big, Mx, 3 * C, 3 * C));
+        if (fq > 0) CK(linear(nb, C, nullptr, 0, qkv, nullptr, nullptr, big, Mx, 3 * C, 3 * C));
         {
             AttnArgs a;
             a.q = big; a.ldq = 3 * C;
@@ -266,8 +287,14 @@ struct Walk {
         }
         CK(linear(pre ? abh : ab, C, nullptr, 0, o1w, o1b, hbx, hbx, Mx, C, C));
         // cross-attention against the prompt context: batch element b uses ctx[b % 2]
-        CK(ln(hbx, l2w, l2b, nb, Mx, C));
-        CK(linear(nb, C, nullptr, 0, q2w, nullptr, nullptr, pre ? abh : ab, Mx, C, C));
+        {
+            const int f2 = ln_proj(hbx, l2w, l2b, b + "attn2.to_q.stream", pre ? abh : ab, Mx, C);
+            if (f2 < 0) return f2;
+            if (f2 > 0) {
+                CK(ln(hbx, l2w, l2b, nb, Mx, C));
+                CK(linear(nb, C, nullptr, 0, q2w, nullptr, nullptr, pre ? abh : ab, Mx, C, C));
+            }
+        }
         if (pre) {
             // the two CFG halves part here: [image] -> [image][cfg] for the residual stream, the query and the block input
             B2 = Bfull;
@@ -560,6 +587,22 @@ int dsim_unet_finalize(dsim_unet* h, void* stream) {
             CK(h->dalloc(P.bytes, &P.p));
             CK(pack_ff_stream(h->pk[k].p, w2->p, P.p, C, s));
             h->pk[b + "ff.stream"] = P;
+        }
+        // LayerNorm-fronted projections of the same blocks: norm1 -> to_q|to_k|to_v and norm2 -> attn2.to_q
+        std::vector<std::pair<std::string, std::string>> lps;
+        for (auto& kv : h->pk) {
+            if (ends_with(kv.first, "attn1.qkv") && rowlin_stream_bytes(kv.second.cols, kv.second.rows))
+                lps.push_back({kv.first, kv.first + ".stream"});
+            if (ends_with(kv.first, "attn2.to_q.weight") && rowlin_stream_bytes(kv.second.cols, kv.second.rows))
+                lps.push_back({kv.first, kv.first.substr(0, kv.first.size() - strlen("weight")) + "stream"});
+        }
+        for (auto& kn : lps) {
+            const Packed& W = h->pk[kn.first];
+            Packed P;
+            P.rows = W.rows; P.cols = W.cols; P.bytes = rowlin_stream_bytes(W.cols, W.rows);
+            CK(h->dalloc(P.bytes, &P.p));
+            CK(pack_rowlin_stream(W.p, P.p, W.cols, W.rows, s));
+            h->pk[kn.second] = P;
         }
     }
     DSIM_HIP_CHECK(hipStreamSynchronize(s));
@@ -866,6 +909,24 @@ int dsim_op_ff_fused(const void* x, const float* ln_gamma, const float* ln_beta,
     FFArgs a;
     a.x = x; a.out = out; a.ln_g = ln_gamma; a.ln_b = ln_beta; a.stream = st; a.b1 = b1p; a.b2 = b2; a.M = M; a.C = C; a.eps = eps;
     CK(launch_ff_fused(a, s));
+    DSIM_HIP_CHECK(hipStreamSynchronize(s));
+    return DSIM_OK;
+}
+
+int dsim_op_ln_linear(const void* x, const float* ln_gamma, const float* ln_beta, const float* w, void* out, int M, int C, int N,
+                      float eps, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const size_t sb = rowlin_stream_bytes(C, N);
+    if (!sb || !x || !out || !w || !ln_gamma != !ln_beta) return DSIM_ERR_INVALID;
+    Tmp t;
+    void* wp = t.get((size_t)N * C * 2);
+    void* st = t.get(sb);
+    if (!wp || !st) return DSIM_ERR_HIP;
+    CK(pack_linear(w, DSIM_F32, wp, DSIM_BF16, N, C, 0, s));
+    CK(pack_rowlin_stream(wp, st, C, N, s));
+    RowLinArgs a;
+    a.x = x; a.out = out; a.ln_g = ln_gamma; a.ln_b = ln_beta; a.stream = st; a.M = M; a.C = C; a.N = N; a.eps = eps;
+    CK(launch_rowlin(a, s));
     DSIM_HIP_CHECK(hipStreamSynchronize(s));
     return DSIM_OK;
 }

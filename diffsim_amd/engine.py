@@ -372,6 +372,19 @@ def op_ff_fused(x, ln_g, ln_b, w1, b1, w2, b2, eps=1e-5):
     return out
 
 
+def op_ln_linear(x, ln_g, ln_b, w, eps=1e-5):
+    """LayerNorm(x) W^T in one launch (bf16, C = 320, bias-free, N a multiple of 64 up to 960); w [N][C] f32; ln_g = ln_b = None
+    skips the LayerNorm."""
+    L = _lib.lib()
+    _require_cuda(x, ln_g, ln_b, w)
+    M, Cc = x.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    _lib.check(L.dsim_op_ln_linear(x.data_ptr(), _ptr(ln_g), _ptr(ln_b), w.data_ptr(), out.data_ptr(), M, Cc, N, float(eps),
+                                   _stream_ptr()), "op_ln_linear")
+    return out
+
+
 def op_conv3x3(x, w, bias=None, residual=None, stride=1, upsample=False):
     """x: [B][H][W][Cin] token-major; w: [Cout][Cin][3][3] f32."""
     L = _lib.lib()

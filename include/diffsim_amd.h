@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DSIM_ABI_VERSION 5
+#define DSIM_ABI_VERSION 6
 
 typedef enum dsim_status {
     DSIM_OK = 0,
@@ -152,9 +152,12 @@ int  dsim_unet_set_cfg_dedup(dsim_unet* h, int enable);
 /* Which multi-operator kernels replace their unfused chains (bf16 handles; default DSIM_FUSE_ALL).  0 runs every layer as its own
  * launch -- the A/B switch of bench.py --fusion and of the parity tests; results agree to bf16 rounding, not bit for bit.
  * DSIM_FUSE_FF: norm3 -> ff.net.0.proj (GEGLU) -> ff.net.2 -> + residual of a 320-channel BasicTransformerBlock as one launch
- * (hacked_modules.py:118-132). */
-#define DSIM_FUSE_FF  1
-#define DSIM_FUSE_ALL 1
+ * (hacked_modules.py:118-132).
+ * DSIM_FUSE_LNPROJ: the LayerNorm in front of a 320-channel block's self-attention q/k/v projection (norm1 -> to_q|to_k|to_v)
+ * and of its cross-attention query (norm2 -> attn2.to_q) runs inside the projection's launch (hacked_modules.py:88-116). */
+#define DSIM_FUSE_FF     1
+#define DSIM_FUSE_LNPROJ 2
+#define DSIM_FUSE_ALL    3
 int  dsim_unet_set_fusion(dsim_unet* h, int mask);
 /* Latent side of the next dsim_unet_qkv calls (cfg.sample_size is only the default): the reference runs any
  * --image_size through the same weights (argprocess.py:8: default 512 px, SDXL native 1024 px).  `side` must be a
@@ -294,6 +297,11 @@ int dsim_op_attention_fp8(const void* q, int ldq, const void* k, const void* v, 
  * Returns DSIM_ERR_INVALID for a width the fused kernel does not cover.                                                   */
 int dsim_op_ff_fused(const void* x, const float* ln_gamma, const float* ln_beta, const float* w1, const float* b1,
                      const float* w2, const float* b2, void* out, int M, int C, float eps, void* stream);
+/* LayerNorm + bias-free Linear as a single launch (bf16, C = 320, N a multiple of 64 up to 960): out[M][N] = LayerNorm(x) W^T --
+ * norm1 -> to_q|to_k|to_v and norm2 -> attn2.to_q of /root/reference/diffsim/hacked_modules.py:88-116.  w: [N][C] f32;
+ * ln_gamma = ln_beta = NULL skips the LayerNorm.  Returns DSIM_ERR_INVALID for a shape the kernel does not cover.            */
+int dsim_op_ln_linear(const void* x, const float* ln_gamma, const float* ln_beta, const float* w, void* out, int M, int C,
+                      int N, float eps, void* stream);
 
 #ifdef __cplusplus
 }

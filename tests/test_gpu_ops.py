@@ -411,6 +411,37 @@ def test_ff_fused_320(eng, M):
     assert torch.equal(x2, got)
 
 
+@pytest.mark.parametrize("M,N,ln", [(128, 960, True), (96, 320, True), (4096 + 32, 960, True), (40000, 320, True), (1000, 640, False),
+                                    (33, 64, True)])
+def test_ln_linear_320(eng, M, N, ln):
+    """LayerNorm -> bias-free Linear as ONE launch (row-resident kernel, bf16, C = 320): norm1 -> to_q|to_k|to_v (N = 960)
+    and norm2 -> attn2.to_q (N = 320) of hacked_modules.py:88-116, against the fp32 CPU chain and against the two-launch HIP
+    chain it replaces (same rounding points: the normalised row is rounded to bf16 before the GEMM in both)."""
+    C = 320
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, C, generator=g) * 1.5 + 0.3
+    lg, lb = torch.randn(C, generator=g) * 0.2 + 1.0, torch.randn(C, generator=g) * 0.1
+    w = torch.randn(N, C, generator=g) / math.sqrt(C)
+    xq = _q(x, dtype)
+    n = _q(F.layer_norm(xq, (C,), lg, lb, 1e-5), dtype) if ln else xq
+    want = F.linear(n, _q(w, dtype))
+    xd = _dev(x, dtype)
+    got = eng.op_ln_linear(xd, _dev(lg) if ln else None, _dev(lb) if ln else None, _dev(w))
+    assert got.shape == (M, N)
+    _close(got, want, dtype)
+    n_h = eng.op_layernorm(xd, _dev(lg), _dev(lb), 1e-5) if ln else xd
+    ref_h = eng.op_linear(n_h, _dev(w), None, None)
+    d = (got.float() - ref_h.float()).abs().max().item()
+    assert d <= float(want.abs().max()) / 64, d
+    if not ln:
+        assert torch.equal(got, ref_h)         # same MFMA k order, no other rounding point: bit for bit
+    assert torch.equal(got, eng.op_ln_linear(xd, _dev(lg) if ln else None, _dev(lb) if ln else None, _dev(w)))
+    for bad in ((C, 100), (C, 1024), (256, 320)):
+        with pytest.raises(eng._lib.DsimError):
+            eng.op_ln_linear(torch.zeros(8, bad[0], dtype=dtype, device="cuda"), None, None, torch.zeros(bad[1], bad[0], device="cuda"))
+
+
 @pytest.mark.parametrize("D", [40, 64, 80])
 def test_attention_long_keys_fixed_reference_softmax(eng, D):
     """Key sequences >= 2048 take the fixed-reference softmax (the maximum is fixed after key tile 0, later tiles never look

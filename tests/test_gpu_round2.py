@@ -258,10 +258,11 @@ def test_cfg_dedup_is_bit_identical():
 
 
 def test_fused_kernels_agree_with_their_unfused_chains():
-    """dsim_unet_set_fusion: the row-resident feed-forward launch (norm3 -> GEGLU projection -> ff.net.2 -> + residual of
-    the 320-channel blocks) against the three launches it replaces, on the SD1.5 channel plan: the q/k/v of a tap behind
-    both 320-channel transformer blocks and the scores agree to bf16 rounding (same rounding points, other summation
-    order); the switch is a no-op in fp32 mode (no fused kernel there) and the workspace plan follows the mask."""
+    """dsim_unet_set_fusion: the row-resident launches of the 320-channel blocks (DSIM_FUSE_FF: norm3 -> GEGLU projection ->
+    ff.net.2 -> + residual; DSIM_FUSE_LNPROJ: norm1 -> q|k|v projection and norm2 -> attn2.to_q) against the launches they
+    replace, on the SD1.5 channel plan: the q/k/v of a tap behind both 320-channel transformer blocks and the scores agree
+    to bf16 rounding (same rounding points, other summation order), each bit alone and both; the switch is a no-op in fp32
+    mode (no fused kernel there) and the workspace plan follows the mask."""
     from diffsim_amd import _lib
     cfg = C.UNetConfig(sample_size=16)
     keys = [k for k in C.unet_param_shapes(cfg) if not k.startswith(("up_blocks.2", "up_blocks.3", "conv_norm_out", "conv_out"))]
@@ -271,11 +272,13 @@ def test_fused_kernels_agree_with_their_unfused_chains():
     zA, zB = torch.cat([p[0] for p in lat]), torch.cat([p[1] for p in lat])
     n = S.draw_pair_noise(2334, lat[0][0].shape)
     fused, plain = _ds(cfg, sd, torch.bfloat16), _ds(cfg, sd, torch.bfloat16, fusion=0)
+    only_ff, only_ln = _ds(cfg, sd, torch.bfloat16, fusion=_lib.FUSE_FF), _ds(cfg, sd, torch.bfloat16, fusion=_lib.FUSE_LNPROJ)
     for blk, layer in (("down_blocks", 1), ("up_blocks", 0)):
-        a = fused.score_latent_pairs(zA, zB, n[2], n[3], ctx, blk, layer, 600, "cosine")
         b = plain.score_latent_pairs(zA, zB, n[2], n[3], ctx, blk, layer, 600, "cosine")
-        assert (a - b).abs().max().item() <= 2e-3, (blk, layer, a, b)
-        assert torch.equal(a, fused.score_latent_pairs(zA, zB, n[2], n[3], ctx, blk, layer, 600, "cosine"))    # reproducible
+        for ds in (fused, only_ff, only_ln):
+            a = ds.score_latent_pairs(zA, zB, n[2], n[3], ctx, blk, layer, 600, "cosine")
+            assert (a - b).abs().max().item() <= 2e-3, (blk, layer, a, b)
+            assert torch.equal(a, ds.score_latent_pairs(zA, zB, n[2], n[3], ctx, blk, layer, 600, "cosine"))    # reproducible
     ef, ep = fused.engine("down_blocks", 1), plain.engine("down_blocks", 1)
     ef.profile(True); ep.profile(True)
     fused.score_latent_pairs(zA[:1], zB[:1], n[2], n[3], ctx, "down_blocks", 1, 600, "cosine")
@@ -284,7 +287,15 @@ def test_fused_kernels_agree_with_their_unfused_chains():
     fp = [r[0] for r in ep.profile_records()]
     ef.profile(False); ep.profile(False)
     assert ff.count("ff_fused_bf16") == 2 and "ff_fused_bf16" not in fp
-    assert len(fp) - len(ff) == 4              # two blocks x (LayerNorm + GEGLU GEMM + ff.net.2 -> one launch)
+    assert ff.count("ln_linear_bf16") == 4 and "ln_linear_bf16" not in fp
+    # two blocks x ((LayerNorm + GEGLU GEMM + ff.net.2 -> one launch) + 2 x (LayerNorm + projection -> one launch))
+    assert len(fp) - len(ff) == 8
+    el = only_ln.engine("down_blocks", 1)
+    el.profile(True)
+    only_ln.score_latent_pairs(zA[:1], zB[:1], n[2], n[3], ctx, "down_blocks", 1, 600, "cosine")
+    fl = [r[0] for r in el.profile_records()]
+    el.profile(False)
+    assert fl.count("ln_linear_bf16") == 4 and "ff_fused_bf16" not in fl and len(fp) - len(fl) == 4
     with pytest.raises(_lib.DsimError):
         ef.set_fusion(8)
     f32a, f32b = _ds(cfg, sd, torch.float32), _ds(cfg, sd, torch.float32, fusion=0)

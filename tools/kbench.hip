@@ -231,6 +231,78 @@ static void bench_ff(const char* name, int M, int iters, Timer& t, void* zp) {
     HC(hipFree(st)); HC(hipFree(nb)); HC(hipFree(big)); HC(hipFree(out));
 }
 
+// row-resident Linear (rowres.hip) against the launches it replaces: [LayerNorm +] the 320-wide Linear (interleaved rounds)
+__global__ void maxdiff_kernel(const __bf16* a, const __bf16* b, size_t n, float* out) {
+    float m = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf((float)a[i] - (float)b[i]));
+    atomicMax(reinterpret_cast<int*>(out), __float_as_int(m));
+}
+static void bench_rowlin(const char* name, int M, int N, bool ln, int iters, Timer& t, void* zp) {
+    if (!want(name)) return;
+    const int C = 320;
+    void* x = dalloc_bf16((size_t)M * C, 1);
+    void* w = dalloc_bf16((size_t)N * C, 2, 0.05f);
+    float* b = dalloc_f32(N, 4);
+    float* lg = dalloc_f32(C, 6);
+    float* lb = dalloc_f32(C, 7);
+    void *st, *nb, *o1, *o2;
+    float* dd;
+    HC(hipMalloc(&st, rowlin_stream_bytes(C, N)));
+    HC(hipMalloc(&nb, (size_t)M * C * 2));
+    HC(hipMalloc(&o1, (size_t)M * N * 2));
+    HC(hipMalloc(&o2, (size_t)M * N * 2));
+    HC(hipMalloc(&dd, 4));
+    HC(hipMemset(dd, 0, 4));
+    int s0 = pack_rowlin_stream(w, st, C, N, 0), s1 = DSIM_OK;
+    RowLinArgs a;
+    a.x = x; a.out = o1; a.ln_g = ln ? lg : nullptr; a.ln_b = ln ? lb : nullptr; a.stream = st; a.M = M; a.C = C; a.N = N;
+    GemmArgs g;
+    g.A0 = ln ? nb : x; g.C0 = C; g.M = M; g.N = N; g.K = C; g.W = w; g.epi = EPI_NONE; g.out = o2; g.ldo = N; g.zero_page = zp;
+    const int rounds = getenv("KB_ROUNDS") ? atoi(getenv("KB_ROUNDS")) : 5;
+    std::vector<float> mf, ml, mg;
+    for (int r = 0; r < rounds; ++r) {
+        mf.push_back(t.run([&] { s1 |= launch_rowlin(a, 0); }, iters));
+        if (ln) ml.push_back(t.run([&] { s1 |= launch_layernorm(x, lg, lb, nb, M, C, 1e-5f, DSIM_BF16, 0); }, iters));
+        mg.push_back(t.run([&] { s1 |= launch_gemm(g, DSIM_BF16, 0); }, iters));
+    }
+    if (const char* e = getenv("KB_RLDBG")) {       // ablation masks, interleaved with the full kernel
+        std::vector<int> vals{0};
+        std::string l = e;
+        for (size_t pos = 0; pos < l.size();) {
+            size_t nx = l.find(',', pos);
+            if (nx == std::string::npos) nx = l.size();
+            vals.push_back(atoi(l.substr(pos, nx - pos).c_str()));
+            pos = nx + 1;
+        }
+        std::vector<std::vector<float>> ms(vals.size());
+        for (int r = 0; r < rounds; ++r)
+            for (size_t k = 0; k < vals.size(); ++k) {
+                g_rl_dbg = vals[k];
+                ms[k].push_back(t.run([&] { s1 |= launch_rowlin(a, 0); }, iters));
+            }
+        g_rl_dbg = 0;
+        printf("  rowlin ablation median ms:");
+        for (size_t k = 0; k < vals.size(); ++k) {
+            std::sort(ms[k].begin(), ms[k].end());
+            printf("  %d:%.3f", vals[k], ms[k][rounds / 2]);
+        }
+        printf("\n");
+        s1 |= launch_rowlin(a, 0);
+    }
+    hipLaunchKernelGGL(maxdiff_kernel, dim3(1024), dim3(256), 0, 0, (const __bf16*)o1, (const __bf16*)o2, (size_t)M * N, dd);
+    float d = 0.f;
+    HC(hipMemcpy(&d, dd, 4, hipMemcpyDeviceToHost));
+    std::sort(mf.begin(), mf.end()); std::sort(mg.begin(), mg.end());
+    float lnm = 0.f;
+    if (ln) { std::sort(ml.begin(), ml.end()); lnm = ml[rounds / 2]; }
+    const double fl = 2.0 * M * (double)C * N;
+    printf("%-26s M=%7d  rowlin %7.3f ms %6.1f TF | ln %6.3f + gemm %6.3f = %7.3f ms   maxdiff %.4g  st=%d/%d\n", name, M, mf[rounds / 2],
+           fl / mf[rounds / 2] / 1e9, lnm, mg[rounds / 2], lnm + mg[rounds / 2], d, s0, s1);
+    HC(hipFree(x)); HC(hipFree(w)); HC(hipFree(b)); HC(hipFree(lg)); HC(hipFree(lb));
+    HC(hipFree(st)); HC(hipFree(nb)); HC(hipFree(o1)); HC(hipFree(o2)); HC(hipFree(dd));
+}
+
 int main(int argc, char** argv) {
     const int B2 = argc > 1 ? atoi(argv[1]) : 64;
     const int iters = argc > 2 ? atoi(argv[2]) : 10;
@@ -241,6 +313,9 @@ int main(int argc, char** argv) {
     Timer t;
     const int s64 = B2 * 4096, s32 = B2 * 1024, s16 = B2 * 256, s8 = B2 * 64;
     bench_ff("ff_64_320_fused", s64, iters, t, zp);
+    bench_rowlin("rowlin_64_ln_qkv", s64, 960, true, iters, t, zp);
+    bench_rowlin("rowlin_64_ln_q", s64, 320, true, iters, t, zp);
+    bench_rowlin("rowlin_64_q", s64, 320, false, iters, t, zp);
     // ---- 3x3 convs ----
     bench_gemm("conv3_64_320_320", GEMM_CONV3, s64, 320, 320, 64, 64, EPI_NONE, iters, t, zp);
     bench_gemm("conv3_64_320_320_res", GEMM_CONV3, s64, 320, 320, 64, 64, EPI_RESIDUAL, iters, t, zp);

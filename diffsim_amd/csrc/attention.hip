@@ -400,6 +400,313 @@ __device__ __forceinline__ void attend_checked(const QFrags<T, D>& qfr, const T*
     }
 }
 
+// ---- long key sequences: two query blocks per wave, software-pipelined ---------------------------------------------------
+// The 64 x 64 self-attention (4096 keys, d = 40) keeps the MFMA pipe 55 % and the VALU 57 % busy in attn_kernel, but only
+// 22 % of the time both at once (r03 counters): within a wave the tile body is serial -- QK^T MFMAs, then 32 v_exp per lane,
+// then PV MFMAs -- and the other waves of the SIMD are as likely to be in the same phase as in the complementary one.
+// Here the overlap is built into ONE wave's instruction stream.  A wave owns 64 query rows as two 32-column blocks; a key
+// tile is four "units" (query block q, key half j), each QK (NKS MFMAs) -> softmax (16 v_exp + 8 v_cvt_pk per lane) -> PV
+// (2 NDB MFMAs).  The units run as a three-stage pipeline, one step per unit:
+//     step n:   MFMA pipe: PV(unit n-1), QK(unit n+1)     VALU: softmax(unit n)
+// with the v_exp / v_cvt of unit n issued between the MFMAs (pinned by sched_barrier), so the matrix pipe executes while
+// the VALU converts.  The pipeline crosses tile borders (the last step of tile t starts tile t + 1's first QK and the first
+// step of tile t + 1 finishes tile t's last PV), so three K/V tiles are live: a 3-deep LDS ring (58 KB, two workgroups per
+// CU), one barrier per tile.  bf16, fixed-reference softmax (attend<.., FAST>: the maximum of key tile 0), Nk % 64 == 0.
+// DBG: kbench ablation masks (1 no v_exp, 2 no PV MFMAs, 4 no QK MFMAs, 8 no global loads in the loop, 16 no v_cvt); 0 in the product
+template <int D, int DBG = 0>
+__device__ __forceinline__ void attend_pipelined2(const QFrags<bf16, D> (&qfr)[2], const bf16* kb, const bf16* vb, int ldk, int Nk,
+                                                  char* lds0, OAcc<bf16, D> (&oacc)[2], float (&l_out)[2]) {
+    typedef bf16 T;
+    typedef ACfg<T, D> C;
+    constexpr int BUF = 2 * C::TILE;                // one K tile + one V tile
+    constexpr int NM = 2 * C::NDB + C::NKS;         // MFMAs per step
+    QFrags<T, D> qloc[2] = {qfr[0], qfr[1]};
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int koff = l31 * C::RS + half * 16;                                                   // K fragment row of this lane
+    const int voff = C::TILEK + (4 * (g4 >> 1) + (i16 >> 2)) * C::RSV + (16 * (g4 & 1) + 4 * (i16 & 3)) * 2;   // transposed V read
+    f32x16 minit[2];
+    float l_run[2] = {0.f, 0.f};
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qb].b[db][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) minit[qb][r] = 0.f;
+    }
+    const int ntiles = Nk / KT;
+    StageRegs<T, D> sr;
+    __syncthreads();            // a previous user of the buffers (the exact fallback never runs before this)
+    {
+        // ring init: zero padding columns, the ones column of V (row sums out of the PV MFMAs) and of K (KONE)
+        typedef StageRegs<T, D> SR;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        if (D < C::DPL)
+            for (int o = tid * 16; o < 3 * BUF; o += 256 * 16) *reinterpret_cast<u32x4*>(lds0 + o) = z;
+#pragma unroll
+        for (int i = 0; i < SR::N; ++i) {
+            const int idx = tid + i * 256;
+            const int r = idx / SR::CPRD, c = idx - r * SR::CPRD;
+            sr.row[i] = idx < KT * SR::CPRD ? r : KT;
+            sr.goff[i] = (unsigned)r * (unsigned)ldk + (unsigned)c * C::VEC;
+            sr.loff[i] = (unsigned)(r * C::RS + c * 16);
+            sr.lvoff[i] = (unsigned)(C::TILEK + r * C::RSV + c * 16);
+        }
+        if constexpr (C::ONES) {
+            __syncthreads();
+            for (int i = tid; i < KT * 3; i += 256) {
+                const int buf = i / KT, r = i - buf * KT;
+                *reinterpret_cast<u32x4*>(lds0 + buf * BUF + C::TILEK + r * C::RSV + (D / C::VEC) * 16) = one_chunk<T>();
+                if constexpr (C::KONE) *reinterpret_cast<u32x4*>(lds0 + buf * BUF + r * C::RS + (D / C::VEC) * 16) = one_chunk<T>();
+            }
+        }
+    }
+    tile_load<T, D>(sr, kb, vb, ldk, 0, Nk);
+    __syncthreads();
+    tile_store<T, D>(lds0, sr, 0, Nk);
+    tile_load<T, D>(sr, kb, vb, ldk, KT, Nk);
+    __syncthreads();
+
+    auto qk = [&](const char* buf, int q, int j, f32x16& s) {            // S'^T block of unit (q, j)
+        s = minit[q];
+#pragma unroll
+        for (int ks = 0; ks < C::NKS; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(buf + koff + j * 32 * C::RS + ks * 32);
+            mma(kf, qloc[q].f[ks], s);
+        }
+    };
+    auto vfrag = [&](const char* buf, int j, int s2, int db) {
+        const char* pa = buf + voff + (j * 32 + 16 * s2) * C::RSV + db * 64;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa + 8 * C::RSV));
+        bf16x8 vf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+        return vf;
+    };
+    auto pv = [&](const char* buf, int q, int j, const bf16x8 (&pf)[2]) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db)
+                oacc[q].b[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(buf, j, s2, db), pf[s2], oacc[q].b[db], 0, 0, 0);
+    };
+    auto softmax = [&](int q, f32x16& s, bf16x8 (&pf)[2]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+        if constexpr (!C::ONES) {
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) psum += s[r];
+            l_run[q] += psum;
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[f][e] = (bf16)s[8 * f + e];
+    };
+
+    // ---- key tile 0, unpipelined: it fixes every row's reference point -------------------------------------------------
+    bf16x8 pfA[2], pfB[2];
+    f32x16 sA, sB;
+    {
+        f32x16 s0[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) qk(lds0, q, j, s0[q][j]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s0[q][j][r]);
+            tmax = max_halves(tmax);
+            float delta = tmax;
+            if constexpr (C::KONE) {
+                const float m_new = (float)(bf16)delta;            // the value Q's spare slot carries exactly
+                delta = m_new;
+                if (half == 1) qloc[q].f[C::NKS - 1][0] = (bf16)(-m_new);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) minit[q][r] = -delta;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s0[q][j][r] -= delta;
+        }
+        bf16x8 pft[2];
+        softmax(0, s0[0][0], pft); pv(lds0, 0, 0, pft);
+        softmax(0, s0[0][1], pft); pv(lds0, 0, 1, pft);
+        softmax(1, s0[1][0], pft); pv(lds0, 1, 0, pft);
+        softmax(1, s0[1][1], pfB);                          // its PV is the first step's
+    }
+    // The four steps of a tile need only two fragment sets: steps 1 and 2 share X = {V^T(t, j0), K(t, j1)}, step 3 and the
+    // next tile's step 0 share Y = {V^T(t, j1), K(t + 1, j0)}.  Each is read from LDS ONE step before its first use (X during
+    // step 0, Y during step 2), so no MFMA waits on an LDS round trip and every fragment read feeds two query blocks.
+    struct FragSet { bf16x8 vf[2][C::NDB]; bf16x8 kf[C::NKS]; };
+    auto load_set = [&](FragSet& F, const char* vbuf, int pj, const char* kbuf, int kj) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db) F.vf[s2][db] = vfrag(vbuf, pj, s2, db);
+#pragma unroll
+        for (int ks = 0; ks < C::NKS; ++ks) F.kf[ks] = *reinterpret_cast<const bf16x8*>(kbuf + koff + kj * 32 * C::RS + ks * 32);
+    };
+    FragSet X, Y;
+    // tile 1 becomes visible, tile 2 is on its way; the pipeline's first QK
+    tile_store<T, D>(lds0 + BUF, sr, KT, Nk);
+    tile_load<T, D>(sr, kb, vb, ldk, 2 * KT, Nk);
+    __syncthreads();
+    load_set(Y, lds0, 1, lds0 + BUF, 0);
+    sA = minit[0];
+#pragma unroll
+    for (int ks = 0; ks < C::NKS; ++ks) mma(Y.kf[ks], qloc[0].f[ks], sA);
+
+    // One pipeline step: the MFMAs of PV(query block pq; P fragments pin; V^T fragments F.vf) and of QK(query block kq; F.kf)
+    // -> sout, with the softmax of sin -> pout (a unit of query block sq) issued between them.
+    auto step = [&](const FragSet& F, int pq, const bf16x8 (&pin)[2], int kq, f32x16& sout, int sq, f32x16& sin, bf16x8 (&pout)[2]) {
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int EPG = (DBG & 96) == 32 ? 4 : ((DBG & 96) == 64 ? 6 : ((DBG & 96) == 96 ? 8 : (16 + NM - 2) / (NM - 1)));       // v_exp per MFMA over the first NM - 1 groups
+#pragma unroll
+        for (int g = 0; g < NM; ++g) {
+            // QK first: its result is the NEXT step's softmax input (a whole PV group of slack), and the P fragments this step's
+            // PV reads were converted a QK group ago
+            if (g >= C::NKS) {
+                const int s2 = (g - C::NKS) / C::NDB, db = (g - C::NKS) % C::NDB;
+                if (!(DBG & 2)) oacc[pq].b[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.vf[s2][db], pin[s2], oacc[pq].b[db], 0, 0, 0);
+            } else {
+                const int ks = g;
+                if (DBG & 4) { if (ks == 0) sout = minit[kq]; }
+                else if (ks == 0) sout = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.kf[0], qloc[kq].f[0], minit[kq], 0, 0, 0);
+                else sout = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.kf[ks], qloc[kq].f[ks], sout, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = g * EPG; r < (g + 1) * EPG && r < 16; ++r)
+                if (!(DBG & 1)) sin[r] = __builtin_amdgcn_exp2f(sin[r]);
+            // the conversions of a P fragment follow its eight exponentials
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+                if ((g == (8 * f + 7) / EPG + 1) || (g == NM - 1 && (8 * f + 7) / EPG + 1 > NM - 1)) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (!(DBG & 16)) pout[f][e] = (bf16)sin[8 * f + e];
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!C::ONES) {
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) psum += sin[r];
+            l_run[sq] += psum;
+        }
+    };
+
+    const char* bprev = lds0;              // tile t - 1
+    const char* bcur = lds0 + BUF;         // tile t
+    char* bnext = lds0 + 2 * BUF;          // tile t + 1
+    for (int t = 1; t < ntiles; ++t) {
+        // tile t + 1 into the ring slot tile t - 2 left (its last reader was the Y load of iteration t - 2, two barriers
+        // ago); rows past Nk are never stored, and the last iteration's QK of "tile ntiles" reads stale finite data whose
+        // result nobody uses
+        tile_store<T, D>(bnext, sr, (t + 1) * KT, Nk);
+        if (!(DBG & 8)) tile_load<T, D>(sr, kb, vb, ldk, (t + 2) * KT, Nk);
+        __syncthreads();
+        load_set(X, bcur, 0, bcur, 1);
+        step(Y, 1, pfB, 1, sB, 0, sA, pfA);       // PV(q1, j1, t - 1)   QK(q1, j0, t)       softmax(q0, j0, t)
+        step(X, 0, pfA, 0, sA, 1, sB, pfB);       // PV(q0, j0, t)       QK(q0, j1, t)       softmax(q1, j0, t)
+        load_set(Y, bcur, 1, bnext, 0);
+        step(X, 1, pfB, 1, sB, 0, sA, pfA);       // PV(q1, j0, t)       QK(q1, j1, t)       softmax(q0, j1, t)
+        step(Y, 0, pfA, 0, sA, 1, sB, pfB);       // PV(q0, j1, t)       QK(q0, j0, t + 1)   softmax(q1, j1, t)
+        const char* tmp = bprev;
+        bprev = bcur; bcur = bnext; bnext = const_cast<char*>(tmp);
+    }
+    // the last tile's last unit: PV(q1, j1) from the Y fragments
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+            oacc[1].b[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y.vf[s2][db], pfB[s2], oacc[1].b[db], 0, 0, 0);
+    (void)bprev;
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        auto& o = oacc[qb].b;
+        float l_tot;
+        if constexpr (C::ONES) {
+            constexpr int RB = D / 32, RR = D % 32;
+            constexpr int RH = (RR >> 2) & 1, REG = (RR & 3) + 4 * (RR >> 3);
+            const float mine = o[RB][REG];
+            const float other = __shfl_xor(mine, 32);
+            l_tot = (half == RH) ? mine : other;
+        } else {
+            l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
+        }
+        l_out[qb] = l_tot;
+        const float inv = 1.0f / l_tot;
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= inv;
+    }
+}
+
+// grid ceil(Nq/256) * H * B (1-D): a workgroup = 4 waves x 64 query rows
+template <int D, int DBG>
+__global__ __launch_bounds__(256, 2) void attn_long_kernel(const AttnArgs p, const float scale_log2) {
+    typedef bf16 T;
+    typedef ACfg<T, D> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+    const int nqb = (p.Nq + 255) / 256;
+    int bid = blockIdx.x;
+    if (p.xcd_remap) {          // as attn_kernel: the query blocks of one (batch, head) run on one XCD back to back
+        const int nwg = gridDim.x, xcd = bid & 7, qq = nwg >> 3, r = nwg & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + slot;
+    }
+    const int qblk = bid % nqb, bh = bid / nqb;
+    const int h = bh % p.H, b = bh / p.H;
+    QFrags<T, D> qf[2];
+    int q[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        q[qb] = qblk * 256 + wave * 64 + qb * 32 + l31;
+        const int qc = q[qb] < p.Nq ? q[qb] : p.Nq - 1;
+        load_q<T, D>(qf[qb], (const T*)p.q + ((size_t)b * p.Nq + qc) * p.ldq + h * D, half, scale_log2);
+    }
+    const size_t kvoff = (size_t)(b % p.Bkv) * p.Nk * p.ldk + h * D;
+    OAcc<T, D> oa[2];
+    float l[2];
+    attend_pipelined2<D, DBG>(qf, (const T*)p.k + kvoff, (const T*)p.v + kvoff, p.ldk, p.Nk, smem, oa, l);
+    // every row's denominator must be finite and sane (attend_checked): else the workgroup repeats the block exactly
+    const int bad = !(l[0] > 0.25f && l[0] < 1e30f) || !(l[1] > 0.25f && l[1] < 1e30f);
+    if (__syncthreads_or(bad)) {
+        attend<T, D, false>(qf[0], (const T*)p.k + kvoff, (const T*)p.v + kvoff, p.ldk, p.Nk, smem, oa[0]);
+        attend<T, D, false>(qf[1], (const T*)p.k + kvoff, (const T*)p.v + kvoff, p.ldk, p.Nk, smem, oa[1]);
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        if (q[qb] >= p.Nq) continue;
+        T* orow = (T*)p.out + ((size_t)b * p.Nq + q[qb]) * p.ldo + h * D;
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = db * 32 + 8 * g + 4 * half;
+                if (d < D) {
+                    bf16x4 v4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v4[j] = (bf16)oa[qb].b[db][4 * g + j];
+                    *reinterpret_cast<bf16x4*>(orow + d) = v4;
+                }
+            }
+    }
+}
+
 // grid ceil(Nq/128) * H * B (1-D)
 // FASTK: the fixed-reference softmax of attend<.., FAST> (long key sequences; see launch_attn_d)
 template <typename T, int D, bool FASTK>
@@ -542,6 +849,26 @@ int launch_attn_d(const AttnArgs& a, hipStream_t s) {
     // long key sequences (the 64 x 64 self-attention: 64 key tiles per block): the fixed-reference softmax, 6 % faster at
     // 4096 keys x d = 40; short ones (cross-attention's 77 keys, the 16 x 16 level) keep the exact running maximum -- there the
     // end-of-block check costs more than the skipped maxima save
+    if constexpr (sizeof(T) == 2 && D == 40) {
+        // two query blocks per wave where SD1.5's 4096-key level lives (d = 64 would spill: its K fragments and staging are wider)
+        if (a.Nk >= 2048 && a.Nk % KT == 0 && g_attn_q2) {
+            constexpr int LDS3 = 3 * 2 * C::TILE;           // the 3-deep tile ring
+#ifdef DSIM_DEVTOOLS
+            switch (g_attn_dbg) {
+#define X(d) case d: { static DeviceOnce o; auto k = attn_long_kernel<D, d>; CK_ONCE(o, k, LDS3); hipLaunchKernelGGL(k, dim3(((a.Nq + 255) / 256) * a.H * a.B), dim3(256), LDS3, s, a, scale_log2_of(D)); DSIM_HIP_CHECK(hipGetLastError()); return DSIM_OK; }
+                X(8) X(32) X(64) X(96)
+#undef X
+                default: break;
+            }
+#endif
+            static DeviceOnce once2;
+            auto kern = attn_long_kernel<D, 0>;
+            CK_ONCE(once2, kern, LDS3);
+            hipLaunchKernelGGL(kern, dim3(((a.Nq + 255) / 256) * a.H * a.B), dim3(256), LDS3, s, a, scale_log2_of(D));
+            DSIM_HIP_CHECK(hipGetLastError());
+            return DSIM_OK;
+        }
+    }
     if (sizeof(T) == 2 && a.Nk >= 2048) {
         static DeviceOnce oncef;
         auto kern = attn_kernel<T, D, true>;
@@ -598,6 +925,11 @@ int launch_tail_t(const void* q, const void* k, const void* v, const int32_t* ia
 }
 
 }  // namespace
+
+#ifdef DSIM_DEVTOOLS
+int g_attn_q2 = 1;
+int g_attn_dbg = 0;
+#endif
 
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
     const int vec = dtype == DSIM_F32 ? 4 : 8;

@@ -141,6 +141,40 @@ static void bench_attn(const char* name, int B, int Bkv, int H, int Nq, int Nk, 
         a.xcd_remap = 1;
         m1.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
     }
+    if (Nk >= 2048) {                             // one query block per wave (attn_kernel) against two (attn_long_kernel)
+        std::vector<float> q1, q2;
+        for (int r = 0; r < rounds; ++r) {
+            g_attn_q2 = 0;
+            q1.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
+            g_attn_q2 = 1;
+            q2.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
+        }
+        std::sort(q1.begin(), q1.end()); std::sort(q2.begin(), q2.end());
+        if (const char* e = getenv("KB_ATDBG")) {
+            std::vector<int> vals{0};
+            std::string l = e;
+            for (size_t pos = 0; pos < l.size();) {
+                size_t nx = l.find(',', pos);
+                if (nx == std::string::npos) nx = l.size();
+                vals.push_back(atoi(l.substr(pos, nx - pos).c_str()));
+                pos = nx + 1;
+            }
+            std::vector<std::vector<float>> ms(vals.size());
+            for (int r = 0; r < rounds; ++r)
+                for (size_t k = 0; k < vals.size(); ++k) {
+                    g_attn_dbg = vals[k];
+                    ms[k].push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
+                }
+            g_attn_dbg = 0;
+            printf("  attn_long ablation median ms:");
+            for (size_t k = 0; k < vals.size(); ++k) {
+                std::sort(ms[k].begin(), ms[k].end());
+                printf("  %d:%.3f", vals[k], ms[k][rounds / 2]);
+            }
+            printf("\n");
+        }
+        printf("  32 queries per wave %8.3f/%8.3f ms | 64 queries per wave %8.3f/%8.3f ms (min/median)\n", q1[0], q1[rounds / 2], q2[0], q2[rounds / 2]);
+    }
     std::sort(m0.begin(), m0.end()); std::sort(m1.begin(), m1.end());
     const float ms = m1[rounds / 2];
     const double fl = 4.0 * B * H * (double)Nq * Nk * D;

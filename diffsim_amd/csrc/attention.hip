@@ -463,10 +463,35 @@ __device__ __forceinline__ void attend_pipelined2(const QFrags<bf16, D> (&qfr)[2
             }
         }
     }
-    tile_load<T, D>(sr, kb, vb, ldk, 0, Nk);
+    // Nk % KT == 0: every tile is whole, so the staging needs no per-row bounds test -- the only predicate left is "this thread
+    // has a chunk in round i" (KT * CPRD chunks over 256 threads), which is WAVE-uniform (a scalar branch, no exec masking).
+    // Past the end the last tile is refetched into a dead ring slot.
+    constexpr int NCH = KT * StageRegs<T, D>::CPRD;
+    static_assert(NCH % 64 == 0, "whole waves per staging round");
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto stage_load = [&](int t) {
+        const int tt = t < ntiles ? t : ntiles - 1;
+        const T* kt = kb + (size_t)tt * KT * ldk;
+        const T* vt = vb + (size_t)tt * KT * ldk;
+#pragma unroll
+        for (int i = 0; i < StageRegs<T, D>::N; ++i)
+            if (i * 256 + wv * 64 < NCH) {
+                sr.k[i] = *reinterpret_cast<const u32x4*>(kt + sr.goff[i]);
+                sr.v[i] = *reinterpret_cast<const u32x4*>(vt + sr.goff[i]);
+            }
+    };
+    auto stage_store = [&](char* buf) {
+#pragma unroll
+        for (int i = 0; i < StageRegs<T, D>::N; ++i)
+            if (i * 256 + wv * 64 < NCH) {
+                *reinterpret_cast<u32x4*>(buf + sr.loff[i]) = sr.k[i];
+                *reinterpret_cast<u32x4*>(buf + sr.lvoff[i]) = sr.v[i];
+            }
+    };
+    stage_load(0);
     __syncthreads();
-    tile_store<T, D>(lds0, sr, 0, Nk);
-    tile_load<T, D>(sr, kb, vb, ldk, KT, Nk);
+    stage_store(lds0);
+    stage_load(1);
     __syncthreads();
 
     auto qk = [&](const char* buf, int q, int j, f32x16& s) {            // S'^T block of unit (q, j)
@@ -559,8 +584,8 @@ __device__ __forceinline__ void attend_pipelined2(const QFrags<bf16, D> (&qfr)[2
     };
     FragSet X, Y;
     // tile 1 becomes visible, tile 2 is on its way; the pipeline's first QK
-    tile_store<T, D>(lds0 + BUF, sr, KT, Nk);
-    tile_load<T, D>(sr, kb, vb, ldk, 2 * KT, Nk);
+    stage_store(lds0 + BUF);
+    stage_load(2);
     __syncthreads();
     load_set(Y, lds0, 1, lds0 + BUF, 0);
     sA = minit[0];
@@ -613,8 +638,8 @@ __device__ __forceinline__ void attend_pipelined2(const QFrags<bf16, D> (&qfr)[2
         // tile t + 1 into the ring slot tile t - 2 left (its last reader was the Y load of iteration t - 2, two barriers
         // ago); rows past Nk are never stored, and the last iteration's QK of "tile ntiles" reads stale finite data whose
         // result nobody uses
-        tile_store<T, D>(bnext, sr, (t + 1) * KT, Nk);
-        if (!(DBG & 8)) tile_load<T, D>(sr, kb, vb, ldk, (t + 2) * KT, Nk);
+        stage_store(bnext);
+        if (!(DBG & 8)) stage_load(t + 2);
         __syncthreads();
         load_set(X, bcur, 0, bcur, 1);
         step(Y, 1, pfB, 1, sB, 0, sA, pfA);       // PV(q1, j1, t - 1)   QK(q1, j0, t)       softmax(q0, j0, t)

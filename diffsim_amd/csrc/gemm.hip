@@ -449,7 +449,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                 float v[4];
                 if (GEGLU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * gelu_erf(acc[i][j + 2][e]);
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * (sizeof(T) == 2 ? gelu_fast(acc[i][j + 2][e]) : gelu_erf(acc[i][j + 2][e]));
                 } else if (BIAS_INIT) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];

@@ -70,13 +70,6 @@ __global__ void pack_ff_stream_kernel(const bf16* __restrict__ w1p, const bf16* 
     *reinterpret_cast<u32x4*>(stream + (size_t)ci * RCHB + o) = v;
 }
 
-__device__ __forceinline__ float gelu_fast(float x) {
-    // x * sigmoid(x (a + b u + c u^2)) with -log2(e) folded into the constants; u clamped so the odd quintic stays monotone
-    const float u = fminf(x * x, 64.0f);
-    const float t = x * fmaf(u, fmaf(u, 1.01426306e-3f, -0.106775724f), -2.30112134f);
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
-}
-
 struct FFParams {
     const bf16* x;          // [M][320] residual stream (input of the LayerNorm and the residual)
     bf16* out;              // [M][320]; may alias x

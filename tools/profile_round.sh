@@ -46,5 +46,6 @@ python3 bench.py --pixels-in --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out
 python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --fusion 0 --batch-pairs 32 > gpurun_out/bench_${TAG}_unfused.json 2> gpurun_out/bench_${TAG}_unfused.log; echo unfused rc=$?
 python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --dedup-cfg > gpurun_out/bench_${TAG}_dedup_cfg.json 2> gpurun_out/bench_${TAG}_dedup_cfg.log; echo dedup rc=$?
 python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --dump-launches gpurun_out/launches_${TAG}.jsonl > /dev/null 2>&1; echo launches rc=$?
+python3 tools/sweep_batch.py > gpurun_out/batch_sweep_${TAG}.txt 2> gpurun_out/batch_sweep_${TAG}.log; echo sweep rc=$?
 DSIM_DECODE_PROCS=auto python3 tools/files_in_bench.py > gpurun_out/bench_${TAG}_files_in.json 2> gpurun_out/bench_${TAG}_files_in.log; echo files_in rc=$?
 tail -c 400 gpurun_out/bench_${TAG}.json

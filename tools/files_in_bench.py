@@ -2,7 +2,7 @@
 """Development probe: files-in throughput (PNG decode + Lanczos resize on the host thread pool, VAE + text encoder +
 U-Net + tail on the GPU), synthetic weights, random 600x500 PNGs.  Two legs, one JSON line:
   pairs     DiffSim.score_pairs over 64 path pairs with one prompt (the CUTE-style call pattern)
-  triplets  harness.score_path_triplets over 48 (ref, left, right, prompt) rows with 12 distinct per-row prompts, each
+  triplets  harness.score_path_triplets over 192 (ref, left, right, prompt) rows with 12 distinct per-row prompts, each
             encoded once by the CLIP-L-sized text encoder on the device (the NIGHTS call pattern, night_main.py:59-90)"""
 import json
 import os
@@ -76,7 +76,7 @@ for _ in range(4):
     ds.score_latent_pairs(latA, latB, nz, nz, "a photo", "up_blocks", 0, 600, "cosine", batch_pairs=16)
 torch.cuda.synchronize(); unet_ms_per_pair = (time.perf_counter() - t0) / 4 / 16 * 1e3
 
-trip = [(paths[i % 32], paths[(i * 5 + 1) % 32], paths[(i * 11 + 2) % 32], f"An image of a thing number {i % 12}") for i in range(48)]
+trip = [(paths[i % 32], paths[(i * 5 + 1) % 32], paths[(i * 11 + 2) % 32], f"An image of a thing number {i % 12}") for i in range(192)]
 H.score_path_triplets(ds, trip[:12], 512, "up_blocks", [0], 600, 2334, "cosine", batch_triplets=10)
 ds._ctx.clear()
 n_enc[0] = 0

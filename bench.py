@@ -56,6 +56,8 @@ def rocprof_name(fam: str) -> str:
             return f"attn_fp8_kernel<{p[2][1:]}>"
         if fam == "attention_bf16_d40_long":         # the 4096-key level of SD1.5: the pipelined two-query-block kernel
             return "attn_long_kernel<40, 0>"
+        if fam == "attention_bf16_d40":              # what is left of d = 40: the 77-key cross-attentions (short-key kernel)
+            return "attn_short_kernel<40>"
         return f"attn_kernel<{'__bf16' if p[1] == 'bf16' else 'float'}, {p[2][1:]}, {'true' if fam.endswith('_long') else 'false'}>"
     if p[0] == "ff":
         return "ff_fused_kernel<0>"

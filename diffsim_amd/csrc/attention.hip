@@ -783,6 +783,153 @@ __global__ __launch_bounds__(256, (ACfg<T, D>::WPS)) void attn_kernel(const Attn
     }
 }
 
+// ---- short key sequences (the 77-key prompt context of every cross-attention) -------------------------------------------
+// attn_kernel spends most of such a launch around its two key tiles: 38 KB of LDS zero-fill, the staging of K and V, three
+// barriers and an online-softmax loop whose second tile is four fifths padding -- per 128 queries, 65 536 workgroups at the
+// 64 x 64 level (181 TF/s, 2.4 TB/s).  Here the keys (<= 96 = three 32-row blocks) are staged ONCE per workgroup and stay in
+// LDS while the workgroup walks QIT query blocks of its (batch, head) with no barrier in the loop: per block three S^T tiles,
+// ONE softmax pass with the exact row maximum (no running state), PV, normalise, store.  The launch becomes what its bytes say
+// it is: a stream of Q in and O out.  bf16; K / V images in attn_kernel's padded row-major layouts (ones column of V included).
+// The heads of a token share cache lines in Q and O (80 bytes per head at d = 40): the XCD-aware block order that keeps the
+// heads of a batch element on one XCD matters more than anything inside the loop (0.62 -> 0.46 ms at d = 40).
+template <int D>
+__global__ __launch_bounds__(256, (D <= 80 ? 4 : 2)) void attn_short_kernel(const AttnArgs p, const float scale_log2, const int qit) {
+    typedef bf16 T;
+    typedef ACfg<T, D> C;
+    constexpr int KR = 96;                                   // key rows held (three 32-row MFMA blocks)
+    constexpr int CPRD = D / C::VEC;                         // real 16-byte chunks per row
+    constexpr int VOFF = KR * C::RS;                         // V image behind the K image
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int nqc = (p.Nq + 128 * qit - 1) / (128 * qit);    // query chunks per (batch, head)
+    int bid = blockIdx.x;
+    if (p.xcd_remap) {          // as attn_kernel: every XCD a contiguous run of (batch, head, chunk) items -- the heads of a row share cache lines
+        const int nwg = gridDim.x, xcd = bid & 7, qq = nwg >> 3, r = nwg & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + slot;
+    }
+    const int qc = bid % nqc, bh = bid / nqc;
+    const int h = bh % p.H, b = bh / p.H;
+    const size_t kvoff = (size_t)(b % p.Bkv) * p.Nk * p.ldk + h * D;
+    const T* kb = (const T*)p.k + kvoff;
+    const T* vb = (const T*)p.v + kvoff;
+    // ---- stage K and V once: zero image (padding columns, rows >= Nk), then the real chunks and V's ones column ---------
+    {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int o = tid * 16; o < KR * (C::RS + C::RSV); o += 256 * 16) *reinterpret_cast<u32x4*>(smem + o) = z;
+        __syncthreads();
+        for (int idx = tid; idx < p.Nk * CPRD; idx += 256) {
+            const int r = idx / CPRD, c = idx - r * CPRD;
+            const u32x4 kk = *reinterpret_cast<const u32x4*>(kb + (size_t)r * p.ldk + c * C::VEC);
+            const u32x4 vv = *reinterpret_cast<const u32x4*>(vb + (size_t)r * p.ldk + c * C::VEC);
+            *reinterpret_cast<u32x4*>(smem + r * C::RS + c * 16) = kk;
+            *reinterpret_cast<u32x4*>(smem + VOFF + r * C::RSV + c * 16) = vv;
+        }
+        if constexpr (C::ONES)
+            for (int r = tid; r < p.Nk; r += 256) *reinterpret_cast<u32x4*>(smem + VOFF + r * C::RSV + CPRD * 16) = one_chunk<T>();
+        __syncthreads();
+    }
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const char* const kfr = smem + l31 * C::RS + half * 16;
+    const char* const vfr = smem + VOFF + (4 * (g4 >> 1) + (i16 >> 2)) * C::RSV + (16 * (g4 & 1) + 4 * (i16 & 3)) * 2;
+    const int q0 = qc * 128 * qit + wave * 32 + l31;
+    QFrags<T, D> qf;
+    {
+        const int qq = q0 < p.Nq ? q0 : p.Nq - 1;
+        load_q<T, D>(qf, (const T*)p.q + ((size_t)b * p.Nq + qq) * p.ldq + h * D, half, scale_log2);
+    }
+    for (int it = 0; it < qit; ++it) {
+        const int q = q0 + it * 128;
+        if (q - l31 >= p.Nq) break;                          // wave-uniform: this wave's rows are past the end
+        // the next block's Q rows fly while this block computes
+        QFrags<T, D> qn;
+        {
+            const int qq = q + 128 < p.Nq ? q + 128 : p.Nq - 1;
+            load_q<T, D>(qn, (const T*)p.q + ((size_t)b * p.Nq + qq) * p.ldq + h * D, half, scale_log2);
+        }
+        f32x16 s[3];
+#pragma unroll
+        for (int kbk = 0; kbk < 3; ++kbk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kbk][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < C::NKS; ++ks) {
+                bf16x8 kf;
+                lload_frag(kf, kfr + kbk * 32 * C::RS + ks * 32);
+                mma(kf, qf.f[ks], s[kbk]);
+            }
+        }
+        // keys >= Nk never count; exact row maximum over the (<= 96) keys: lane-local + one exchange between the halves
+        float m = -INFINITY;
+#pragma unroll
+        for (int kbk = 0; kbk < 3; ++kbk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = kbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (kv >= p.Nk) s[kbk][r] = -INFINITY;
+                m = fmaxf(m, s[kbk][r]);
+            }
+        m = max_halves(m);
+        float psum = 0.f;
+#pragma unroll
+        for (int kbk = 0; kbk < 3; ++kbk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[kbk][r] = __builtin_amdgcn_exp2f(s[kbk][r] - m);
+                if constexpr (!C::ONES) psum += s[kbk][r];
+            }
+        f32x16 o[C::NDB];
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll
+        for (int kbk = 0; kbk < 3; ++kbk)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (bf16)s[kbk][8 * s2 + e];
+#pragma unroll
+                for (int db = 0; db < C::NDB; ++db) {
+                    const char* pa = vfr + (kbk * 32 + 16 * s2) * C::RSV + db * 64;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa + 8 * C::RSV));
+                    bf16x8 vf;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+                }
+            }
+        float l_tot;
+        if constexpr (C::ONES) {
+            constexpr int RB = D / 32, RR = D % 32;
+            constexpr int RH = (RR >> 2) & 1, REG = (RR & 3) + 4 * (RR >> 3);
+            const float mine = o[RB][REG];
+            const float other = __shfl_xor(mine, 32);
+            l_tot = (half == RH) ? mine : other;
+        } else {
+            l_tot = psum + __shfl_xor(psum, 32);
+        }
+        const float inv = 1.0f / l_tot;
+        if (q < p.Nq) {
+            T* orow = (T*)p.out + ((size_t)b * p.Nq + q) * p.ldo + h * D;
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = db * 32 + 8 * g + 4 * half;
+                    if (d < D) {
+                        bf16x4 v4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v4[e] = (bf16)(o[db][4 * g + e] * inv);
+                        *reinterpret_cast<bf16x4*>(orow + d) = v4;
+                    }
+                }
+        }
+        qf = qn;
+    }
+}
+
 // ---- fused score tail ----------------------------------------------------------------------
 // grid (ceil(N/128), B*H, n_pairs*2); partial layout [pair][dir][bh][qtile][4] f32
 template <typename T, int D>
@@ -874,6 +1021,24 @@ int launch_attn_d(const AttnArgs& a, hipStream_t s) {
     // long key sequences (the 64 x 64 self-attention: 64 key tiles per block): the fixed-reference softmax, 6 % faster at
     // 4096 keys x d = 40; short ones (cross-attention's 77 keys, the 16 x 16 level) keep the exact running maximum -- there the
     // end-of-block check costs more than the skipped maxima save
+    if constexpr (sizeof(T) == 2 && (D == 40 || D == 80)) {
+        // the prompt context of the cross-attentions (77 keys): keys resident in LDS, several query blocks per workgroup
+        // (interleaved A/B at 64 pairs: d = 40 0.502 -> 0.464 ms, d = 80 0.257 -> 0.227 ms; d = 160 at 256 queries: no gain, not used)
+        if (a.Nk <= 96 && g_attn_short) {
+            constexpr int LDSS = 96 * (C::RS + C::RSV);
+            static DeviceOnce onces;
+            auto kern = attn_short_kernel<D>;
+            CK_ONCE(onces, kern, LDSS);
+            // query blocks per workgroup: as many as keep >= 8 workgroups per CU in the grid (at most 8)
+            const int nqb = (a.Nq + 127) / 128;
+            int qit = 8;
+            while (qit > 1 && (long)((nqb + qit - 1) / qit) * a.H * a.B < 8L * cu_count()) qit >>= 1;
+            const int nqc = (nqb + qit - 1) / qit;
+            hipLaunchKernelGGL(kern, dim3(nqc * a.H * a.B), dim3(256), LDSS, s, a, scale_log2_of(D), qit);
+            DSIM_HIP_CHECK(hipGetLastError());
+            return DSIM_OK;
+        }
+    }
     if constexpr (sizeof(T) == 2 && D == 40) {
         // two query blocks per wave where SD1.5's 4096-key level lives (d = 64 would spill: its K fragments and staging are wider)
         if (a.Nk >= 2048 && a.Nk % KT == 0 && g_attn_q2) {
@@ -954,6 +1119,7 @@ int launch_tail_t(const void* q, const void* k, const void* v, const int32_t* ia
 #ifdef DSIM_DEVTOOLS
 int g_attn_q2 = 1;
 int g_attn_dbg = 0;
+int g_attn_short = 1;
 #endif
 
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {

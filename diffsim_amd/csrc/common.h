@@ -86,11 +86,12 @@ extern int g_ln_rows;           // DSIM_LN_ROWS
 extern int g_prep8;             // DSIM_PREP8
 extern int g_attn_q2;           // 0 = long-key attention with one query block per wave (attn_kernel)
 extern int g_attn_dbg;          // ablation mask of attn_long_kernel
+extern int g_attn_short;        // 0 = short key sequences through attn_kernel
 extern int g_ff_dbg;            // ablation mask of the fused feed-forward kernel (rowres.hip)
 extern int g_rl_dbg;            // ablation mask of the row-resident Linear kernel (rowres.hip)
 extern int g_ff_stagger;        // its wave de-phasing, in s_nop 7 units per wave index
 #else
-constexpr int g_gemm_persistent = 1, g_force_bm = 0, g_gn_onepass = 1, g_ln_rows = 1, g_prep8 = 1, g_attn_q2 = 1;
+constexpr int g_gemm_persistent = 1, g_force_bm = 0, g_gn_onepass = 1, g_ln_rows = 1, g_prep8 = 1, g_attn_q2 = 1, g_attn_short = 1;
 #endif
 void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn);   // which template instantiation launch_gemm picks
 

@@ -160,7 +160,9 @@ def test_layernorm(eng, dtype, M, C):
     # ragged key counts around the 32-key MFMA blocks and the 64-key tiles for every production head dim, the 77-key
     # cross-attention shapes, a single tile, many tiles
     (2, 2, 8, 300, 77, 40), (4, 2, 5, 200, 77, 64), (2, 2, 4, 130, 200, 72), (2, 2, 4, 96, 31, 80), (2, 2, 2, 64, 33, 40),
-    (2, 1, 2, 64, 64, 40), (2, 2, 2, 128, 65, 64), (1, 1, 2, 160, 97, 40), (2, 2, 2, 96, 129, 80), (1, 1, 3, 64, 449, 72)])
+    (2, 1, 2, 64, 64, 40), (2, 2, 2, 128, 65, 64), (1, 1, 2, 160, 97, 40), (2, 2, 2, 96, 129, 80), (1, 1, 3, 64, 449, 72),
+    # the short-key kernel (bf16, <= 96 keys, d = 40 / 80) with several query blocks per workgroup and a ragged last block
+    (16, 2, 8, 4096 + 40, 77, 40), (32, 2, 8, 1024 + 7, 77, 80), (2, 2, 8, 512, 96, 40)])
 def test_attention(eng, dtype, B, Bkv, H, Nq, Nk, D):
     g = torch.Generator().manual_seed(Nq + Nk + D)
     q = torch.randn(B, Nq, H * D, generator=g) * 1.3

@@ -141,6 +141,17 @@ static void bench_attn(const char* name, int B, int Bkv, int H, int Nq, int Nk, 
         a.xcd_remap = 1;
         m1.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
     }
+    if (Nk <= 96) {                               // keys resident in LDS (attn_short_kernel) against the tiled kernel
+        std::vector<float> q1, q2;
+        for (int r = 0; r < rounds; ++r) {
+            g_attn_short = 0;
+            q1.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
+            g_attn_short = 1;
+            q2.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
+        }
+        std::sort(q1.begin(), q1.end()); std::sort(q2.begin(), q2.end());
+        printf("  tiled kernel %8.3f/%8.3f ms | short-key kernel %8.3f/%8.3f ms (min/median)\n", q1[0], q1[rounds / 2], q2[0], q2[rounds / 2]);
+    }
     if (Nk >= 2048) {                             // one query block per wave (attn_kernel) against two (attn_long_kernel)
         std::vector<float> q1, q2;
         for (int r = 0; r < rounds; ++r) {
@@ -380,6 +391,7 @@ int main(int argc, char** argv) {
     bench_attn("attn_self_1024_d80", B2, B2, 8, 1024, 1024, 80, iters, t);
     bench_attn("attn_self_256_d160", B2, B2, 8, 256, 256, 160, iters, t);
     bench_attn("attn_cross_4096_d40", B2, 2, 8, 4096, 77, 40, iters, t);
+    bench_attn("attn_cross_1024_d80", B2, 2, 8, 1024, 77, 80, iters, t);
     bench_attn("attn_cross_256_d160", B2, 2, 8, 256, 77, 160, iters, t);
     // ---- norms ----
     bench_gn("gn_64_320", B2, 4096, 320, iters, t);

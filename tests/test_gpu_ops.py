@@ -162,7 +162,9 @@ def test_layernorm(eng, dtype, M, C):
     (2, 2, 8, 300, 77, 40), (4, 2, 5, 200, 77, 64), (2, 2, 4, 130, 200, 72), (2, 2, 4, 96, 31, 80), (2, 2, 2, 64, 33, 40),
     (2, 1, 2, 64, 64, 40), (2, 2, 2, 128, 65, 64), (1, 1, 2, 160, 97, 40), (2, 2, 2, 96, 129, 80), (1, 1, 3, 64, 449, 72),
     # the short-key kernel (bf16, <= 96 keys, d = 40 / 80) with several query blocks per workgroup and a ragged last block
-    (16, 2, 8, 4096 + 40, 77, 40), (32, 2, 8, 1024 + 7, 77, 80), (2, 2, 8, 512, 96, 40)])
+    (16, 2, 8, 4096 + 40, 77, 40), (32, 2, 8, 1024 + 7, 77, 80), (2, 2, 8, 512, 96, 40),
+    # the pipelined long-key kernel (bf16, d = 40, keys a multiple of 64 and >= 2048) with a ragged last query block
+    (1, 1, 2, 300, 2112, 40), (2, 1, 3, 257, 2048, 40)])
 def test_attention(eng, dtype, B, Bkv, H, Nq, Nk, D):
     g = torch.Generator().manual_seed(Nq + Nk + D)
     q = torch.randn(B, Nq, H * D, generator=g) * 1.3

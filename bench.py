@@ -66,19 +66,45 @@ def rocprof_name(fam: str) -> str:
     return fam           # groupnorm / layernorm families span several kernel symbols
 
 
-def _newest_pmc(suffix: str, kernel: str, field: str):
-    """`field` of `kernel` from the newest committed rocprofv3 PMC summary profiles/rNN*_<suffix>.json that lists it
-    (separate --pmc passes of this same command, gfx950 FETCH_SIZE x2 correction applied: profiles/summarize.py).
-    PMC counters cannot be read from inside a normal run, so this is the committed measurement, or None."""
-    import glob
-    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{suffix}.json")))):
+PMC_MODEL = "sd15"          # which model's PMC passes the roofline fields of this run read (set by main())
+
+
+def pmc_file_class(model: str, suffix: str):
+    """Exact file-name class of a committed PMC summary: profiles/rNN[x]_<suffix>.json for the headline (SD1.5) passes,
+    profiles/rNN[x]_sdxl_<suffix>.json / ..._dit_<suffix>.json for the secondary models.  Never a substring glob: the
+    SDXL and DiT passes launch kernels with the same symbols as the SD1.5 pass, on other shapes."""
+    import re
+    mid = "" if model == "sd15" else re.escape(model) + "_"
+    return re.compile(r"^r(\d+)([a-z]*)_" + mid + re.escape(suffix) + r"\.json$")
+
+
+def newest_pmc_file(model: str, suffix: str, kernel: str = None):
+    """Newest (round number, then letter) committed summary of `model`'s `suffix` pass that lists `kernel`; None if none."""
+    pat = pmc_file_class(model, suffix)
+    pdir = os.path.join(ROOT, "profiles")
+    cands = []
+    for fn in os.listdir(pdir) if os.path.isdir(pdir) else []:
+        m = pat.match(fn)
+        if m:
+            cands.append(((int(m.group(1)), m.group(2)), fn))
+    for _key, fn in sorted(cands, reverse=True):
         try:
-            d = json.load(open(f))
+            d = json.load(open(os.path.join(pdir, fn)))
         except Exception:
             continue
-        if kernel in d:
-            return d[kernel][field]
+        if kernel is None or kernel in d:
+            return os.path.join(pdir, fn)
     return None
+
+
+def _newest_pmc(suffix: str, kernel: str, field: str):
+    """`field` of `kernel` from the newest committed rocprofv3 PMC summary of THIS model's pass (separate --pmc passes of
+    this same command, gfx950 FETCH_SIZE x2 correction applied: profiles/summarize.py).  PMC counters cannot be read
+    from inside a normal run, so this is the committed measurement, or None."""
+    f = newest_pmc_file(PMC_MODEL, suffix, kernel)
+    if f is None:
+        return None
+    return json.load(open(f))[kernel][field]
 
 
 def pmc_traffic(kernel: str):
@@ -499,6 +525,8 @@ def main():
         # every rank builds the same synthetic weights on the host: share the cores instead of oversubscribing them
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
         dist.init_process_group("nccl", device_id=dev)
+    global PMC_MODEL
+    PMC_MODEL = a.model
     if a.model != "sd15":
         secondary(a, world, rank, dev)
     else:

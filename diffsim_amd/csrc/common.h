@@ -93,6 +93,7 @@ extern int g_ff_stagger;        // its wave de-phasing, in s_nop 7 units per wav
 #else
 constexpr int g_gemm_persistent = 1, g_force_bm = 0, g_gn_onepass = 1, g_ln_rows = 1, g_prep8 = 1, g_attn_q2 = 1, g_attn_short = 1;
 #endif
+int gemm_band_width(int tilesM, int tilesN, size_t w_tile_bytes);   // tile-order band width (L2 reuse of the weight tiles)
 void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn);   // which template instantiation launch_gemm picks
 
 // weight repack kernels -- pack.hip  (src f32/bf16/f16 diffusers layout -> packed compute dtype)

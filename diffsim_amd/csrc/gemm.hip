@@ -22,6 +22,8 @@
 // transpose, next tile's first stage in flight under the epilogue.
 #include "common.h"
 
+#include <algorithm>
+
 namespace dsim {
 
 #ifdef DSIM_DEVTOOLS
@@ -141,7 +143,8 @@ constexpr int gemm_lds_bytes() {
 // every prefetched residual register in scratch, and the DiT math would add its register pressure to all users.
 enum { EK_PLAIN = 0, EK_RES = 1, EK_SLOW = 2, EK_ACT = 3 };   // EK_ACT: tanh-GELU only (DiT Mlp.fc1): no gate, no residual registers
 template <typename T, int BM, int BN, int MODE, bool GEGLU, int WM, int WN, int EK>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p, const int tilesN, const int ntiles) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p, const int tilesN, const int ntiles, const int tilesM,
+                                                               const int gn) {
     constexpr int NW = WM * WN;
     constexpr int BK = Traits<T>::BK;
     constexpr int VEC = Traits<T>::VEC;
@@ -182,12 +185,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     const int Hv = p.Hin << p.ups, Wv = p.Win << p.ups;
     auto setup = [&](int vb) {
         // XCD-aware bijective remap: the 8 XCDs take consecutive block ids round-robin (gridDim.x is a multiple
-        // of 8 whenever a workgroup walks more than one tile); give each XCD a contiguous run of logical tiles so
-        // that tiles sharing an A panel share an L2.
+        // of 8 whenever a workgroup walks more than one tile); give each XCD a contiguous run of logical tiles, and order
+        // the logical tiles in column BANDS of gn tile columns, row panel by row panel inside a band: the ~32 workgroups an
+        // XCD runs at one time then cover (32 / gn) activation panels x gn weight tiles instead of one panel x 32 weight
+        // tiles, and the band's weight tiles stay in the XCD's 4 MiB L2 for the whole sweep down M (gemm_band_width()).
         const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7, slot = vb >> 3;
         const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-        m0 = (bid / tilesN) * BM;
-        n0 = (bid % tilesN) * BN;
+        const int band = bid / (gn * tilesM), rem = bid - band * (gn * tilesM);
+        const int bw = min(gn, tilesN - band * gn);            // the last band may be narrower
+        const int mt = rem / bw;
+        m0 = mt * BM;
+        n0 = (band * gn + (rem - mt * bw)) * BN;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int m = m0 + i * (NW * 8) + wrow;
@@ -564,6 +572,24 @@ int cu_count() {
     return n;
 }
 
+// Width (in tile columns) of the column bands the logical tile order walks (gemm_kernel setup()).  An XCD runs ~32 tiles at
+// a time; in row-major order at N = 10240 (40 tile columns) those are one activation panel x 32 different weight tiles,
+// 21 MB of weights against a 4 MiB L2: every tile re-fetched its whole weight tile over the fabric (7.3 GB per launch
+// measured for 1.1 GB algorithmic).  With bands of gn columns the concurrent set is (32 / gn) panels x gn weight tiles
+// and the band's weights (gn x BN x K) are re-used from L2 down the whole M sweep; the activations are then read
+// tilesN / gn times.  gn = the widest band whose weight tiles fit in about half the L2, at least 2 and at most 8.
+// Per-tile arithmetic is untouched: outputs are bit-identical for every gn.
+int gemm_band_width(int tilesM, int tilesN, size_t w_tile_bytes) {
+    (void)tilesM;
+    if (tilesN <= 4) return tilesN;                        // already one band (row-major order)
+    int gn = (int)((size_t)(2560 * 1024) / (w_tile_bytes ? w_tile_bytes : 1));
+    gn = gn < 2 ? 2 : (gn > 8 ? 8 : gn);
+    // even out the bands: N = 12 tile columns at gn = 5 -> 3 bands of 4, not 5 + 5 + 2
+    const int bands = (tilesN + gn - 1) / gn;
+    gn = (tilesN + bands - 1) / bands;
+    return gn;
+}
+
 namespace {
 
 template <typename T, int BM, int BN, int MODE, bool GEGLU, int WM, int WN, int EK>
@@ -597,7 +623,11 @@ int launch_ek(const GemmArgs& a, hipStream_t s) {
     const int ntiles = tilesM * tilesN;
     const int resident = ((cu_count() * (LDS <= 80 * 1024 ? 2 : 1)) / 8) * 8;
     const int grid = ntiles <= resident || resident < 8 || !g_gemm_persistent ? ntiles : resident;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, s, g, tilesN, ntiles);
+    int gn = gemm_band_width(tilesM, tilesN, (size_t)BN * a.K * es);
+#ifdef DSIM_DEVTOOLS
+    if (g_gemm_exp >> 16) gn = std::min(tilesN, g_gemm_exp >> 16);      // kbench: KB_GEXP = gn << 16 (>= tilesN: row-major order)
+#endif
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), LDS, s, g, tilesN, ntiles, tilesM, gn);
     DSIM_HIP_CHECK(hipGetLastError());
     return DSIM_OK;
 }

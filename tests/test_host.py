@@ -149,6 +149,42 @@ def test_bench_kernel_names_match_the_committed_rocprof_summaries():
     assert bench.pmc_traffic(line["roofline"]["kernel"]) and bench.pmc_mfma_util(line["roofline"]["kernel"])
 
 
+def test_bench_pmc_fields_come_from_the_pass_of_the_same_model():
+    """roofline.traffic / mfma_util_pmc of a bench line are read from the newest committed PMC summary OF THAT MODEL:
+    the SDXL and DiT passes list the same kernel symbols as the SD1.5 pass (on other shapes), so the lookup goes by exact
+    file-name class, never by a glob that the lexically last file wins."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.pmc_file_class("sd15", "pmc_hbm").match("r03d_pmc_hbm.json")
+    assert not bench.pmc_file_class("sd15", "pmc_hbm").match("r03d_sdxl_pmc_hbm.json")
+    assert not bench.pmc_file_class("sd15", "pmc_hbm").match("r03d_dit_pmc_hbm.json")
+    assert bench.pmc_file_class("sdxl", "pmc_hbm").match("r03d_sdxl_pmc_hbm.json")
+    assert not bench.pmc_file_class("dit", "pmc_mfma").match("r03d_pmc_mfma.json")
+    # r10a sorts after r9z: round number first, then the letter
+    for model in ("sd15", "sdxl", "dit"):
+        bench.PMC_MODEL = model
+        for suffix, field, fn in (("pmc_hbm", "hbm_bytes_per_launch", bench.pmc_traffic), ("pmc_mfma", "mfma_util", bench.pmc_mfma_util)):
+            f = bench.newest_pmc_file(model, suffix)
+            assert f is not None, (model, suffix)
+            base = os.path.basename(f)
+            assert ("_sdxl_" in base) == (model == "sdxl") and ("_dit_" in base) == (model == "dit"), base
+            d = json.load(open(f))
+            for kernel in d:
+                f2 = bench.newest_pmc_file(model, suffix, kernel)
+                assert fn(kernel) == json.load(open(f2))[kernel][field]
+    # the headline line of the newest committed snapshot: its traffic is the SD1.5 pass's number for the roofline kernel
+    bench.PMC_MODEL = "sd15"
+    f = bench.newest_pmc_file("sd15", "pmc_hbm")
+    tag = os.path.basename(f).split("_")[0]
+    bl = os.path.join(root, "profiles", f"{tag}_bench.json")
+    if os.path.exists(bl) and int(re.match(r"r(\d+)", tag).group(1)) >= 4:      # lines before round 4 carry the old lookup
+        line = json.load(open(bl))
+        assert line["roofline"]["traffic"] == json.load(open(f))[line["roofline"]["kernel"]]["hbm_bytes_per_launch"]
+
+
 def test_public_header_is_plain_c99(tmp_path):
     """The drop-in boundary is a C ABI: include/diffsim_amd.h must compile as C99 with no C++ or torch types."""
     import shutil

@@ -30,6 +30,18 @@ __global__ void fill_f32(float* p, size_t n, unsigned seed, float scale) {
     p[i] = ((float)(x & 0xffff) / 32768.0f - 1.0f) * scale;
 }
 
+__global__ void maxdiff_kernel(const __bf16* a, const __bf16* b, size_t n, float* out) {
+    float m = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf((float)a[i] - (float)b[i]));
+    atomicMax(reinterpret_cast<int*>(out), __float_as_int(m));
+}
+// bitwise difference count of two buffers (tile-order experiments must not change a single output bit)
+__global__ void bitdiff_kernel(const unsigned short* a, const unsigned short* b, size_t n, unsigned* out) {
+    unsigned c = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += a[i] != b[i];
+    if (c) atomicAdd(out, c);
+}
 static void* dalloc_bf16(size_t n, unsigned seed, float scale = 1.0f) {
     void* p;
     HC(hipMalloc(&p, n * 2 + 256));
@@ -105,11 +117,29 @@ static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H,
                 g_gemm_exp = masks[k];
                 ms[k].push_back(t.run([&] { st = launch_gemm(g, DSIM_BF16, 0); }, iters));
             }
+        // outputs of every mask against mask 0, bit for bit
+        void* ref;
+        unsigned* dcount;
+        HC(hipMalloc(&ref, (size_t)M * outc * 2));
+        HC(hipMalloc((void**)&dcount, 4));
         g_gemm_exp = 0;
-        printf("  gemm exp min/median ms:");
+        st = launch_gemm(g, DSIM_BF16, 0);
+        HC(hipMemcpy(ref, out, (size_t)M * outc * 2, hipMemcpyDeviceToDevice));
+        std::vector<unsigned> nd(masks.size(), 0);
+        for (size_t k = 1; k < masks.size(); ++k) {
+            g_gemm_exp = masks[k];
+            HC(hipMemset(out, 0xff, (size_t)M * outc * 2));
+            st = launch_gemm(g, DSIM_BF16, 0);
+            HC(hipMemset(dcount, 0, 4));
+            hipLaunchKernelGGL(bitdiff_kernel, dim3(1024), dim3(256), 0, 0, (const unsigned short*)out, (const unsigned short*)ref, (size_t)M * outc, dcount);
+            HC(hipMemcpy(&nd[k], dcount, 4, hipMemcpyDeviceToHost));
+        }
+        HC(hipFree(ref)); HC(hipFree(dcount));
+        g_gemm_exp = 0;
+        printf("  gemm exp min/median ms [differing outputs]:");
         for (size_t k = 0; k < masks.size(); ++k) {
             std::sort(ms[k].begin(), ms[k].end());
-            printf("  %d:%.3f/%.3f", masks[k], ms[k][0], ms[k][rounds / 2]);
+            printf("  %d:%.3f/%.3f [%u]", masks[k], ms[k][0], ms[k][rounds / 2], nd[k]);
         }
         printf("\n");
     }
@@ -277,12 +307,6 @@ static void bench_ff(const char* name, int M, int iters, Timer& t, void* zp) {
 }
 
 // row-resident Linear (rowres.hip) against the launches it replaces: [LayerNorm +] the 320-wide Linear (interleaved rounds)
-__global__ void maxdiff_kernel(const __bf16* a, const __bf16* b, size_t n, float* out) {
-    float m = 0.f;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        m = fmaxf(m, fabsf((float)a[i] - (float)b[i]));
-    atomicMax(reinterpret_cast<int*>(out), __float_as_int(m));
-}
 static void bench_rowlin(const char* name, int M, int N, bool ln, int iters, Timer& t, void* zp) {
     if (!want(name)) return;
     const int C = 320;
@@ -352,6 +376,7 @@ int main(int argc, char** argv) {
     const int B2 = argc > 1 ? atoi(argv[1]) : 64;
     const int iters = argc > 2 ? atoi(argv[2]) : 10;
     g_filter = argc > 3 ? argv[3] : nullptr;
+    if (const char* e = getenv("KB_ONEEXP")) g_gemm_exp = atoi(e);      // one GEMM experiment mask for the whole run (PMC passes)
     void* zp;
     HC(hipMalloc(&zp, 256));
     HC(hipMemset(zp, 0, 256));

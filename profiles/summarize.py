@@ -98,6 +98,8 @@ def main():
             e = acc[short(dm3[r["Kernel_Name"]])]
             e[r["Counter_Name"]] += float(r["Counter_Value"])
             e["n_" + r["Counter_Name"]] += 1
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("End_Timestamp") and r.get("Start_Timestamp"):
+                e["ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
         mf = {}
         for k, e in acc.items():
             n = max(e["n_GRBM_GUI_ACTIVE"], 1)
@@ -105,6 +107,10 @@ def main():
             busy = e["SQ_VALU_MFMA_BUSY_CYCLES"] / max(e["n_SQ_VALU_MFMA_BUSY_CYCLES"], 1)
             mf[k] = {"launches": int(n), "cycles_per_launch": int(cyc), "mfma_busy_cycles_per_launch": int(busy),
                      "mfma_util": round(busy / (cyc * 1024.0), 4) if cyc else None}
+            if e.get("ns"):
+                # clock the chip held during this kernel IN THIS (profiled, serialised) pass: GRBM_GUI_ACTIVE / 8 XCDs over the
+                # dispatch's own begin/end timestamps (reads high on dispatches shorter than ~0.3 ms: MI355X_MICROARCH.md DVFS)
+                mf[k]["held_clock_ghz"] = round(e["GRBM_GUI_ACTIVE"] / 8.0 / e["ns"], 3)
         json.dump(mf, open(os.path.join(HERE, f"{tag}_pmc_mfma.json"), "w"), indent=1, sort_keys=True)
     print("wrote", tag)
 

@@ -446,6 +446,46 @@ def test_ln_linear_320(eng, M, N, ln):
             eng.op_ln_linear(torch.zeros(8, bad[0], dtype=dtype, device="cuda"), None, None, torch.zeros(bad[1], bad[0], device="cuda"))
 
 
+@pytest.mark.parametrize("Nq,Nk", [(300, 2048), (256, 4096), (300, 4096)])
+def test_attention_pipelined_kernel_takes_the_exact_fallback(eng, Nq, Nk):
+    """attn_long_kernel itself (bf16, d = 40, Nk >= 2048 and Nk % 64 == 0: SD1.5's 4096-key self-attention, the headline path)
+    through its exact-softmax fallback: the forced cases of test_attention_long_keys_fixed_reference_softmax use Nk = 2048 + 77,
+    which routes to attn_kernel / attend_checked.  Here the spike sits at a key far down a sequence the pipelined kernel owns, so
+    its __syncthreads_or(bad) and the two exact re-runs over the 3-deep ring execute; ragged Nq exercises the partial last
+    query block through the same path.  The spiked workgroup and an un-spiked one (other head, other query block) are checked."""
+    dtype = torch.bfloat16
+    B, H, D = 1, 2, 40
+    g = torch.Generator().manual_seed(Nq + Nk)
+    q = torch.randn(B, Nq, H * D, generator=g)
+    k = torch.randn(B, Nk, H * D, generator=g)
+    v = torch.randn(B, Nk, H * D, generator=g)
+    key = Nk - 500
+    rows = (7, Nq - 3)                      # one row in the first query block, one in the (ragged) last
+    for case, boost in (("plain", 0.0), ("late spike", 28.0), ("overflow", 210.0)):
+        kk = k.clone()
+        qq = q.clone()
+        if boost:
+            # both spiked rows share one direction in head 0, so ONE key gives both the logit `boost` (natural units)
+            qq[0, rows[1], :D] = qq[0, rows[0], :D]
+            q7 = qq[0, rows[0], :D]
+            kk[0, key, :D] = boost * q7 / (q7.norm() ** 2) * math.sqrt(D)
+        qh, kh, vh = (_q(t, dtype) for t in (qq, kk, v))
+        want = F.scaled_dot_product_attention(qh.double().view(B, Nq, H, D).transpose(1, 2), kh.double().view(B, Nk, H, D).transpose(1, 2),
+                                              vh.double().view(B, Nk, H, D).transpose(1, 2)).transpose(1, 2).reshape(B, Nq, H * D).float()
+        got = eng.op_attention(_dev(qq, dtype), _dev(kk, dtype), _dev(v, dtype), H)
+        assert got.shape == (B, Nq, H * D)
+        assert torch.isfinite(got.float()).all(), case
+        if case == "overflow":
+            assert (got.float().cpu() - want).abs().max().item() <= 5e-2 * float(want.abs().max())
+        else:
+            _close(got, want, dtype)
+        # head 1 never sees the spike: the same numbers whichever path its neighbour took
+        _close(got[..., D:], want[..., D:], dtype)
+        if boost:
+            for r in rows:                  # the spiked rows are one-hot on `key`
+                assert (got[0, r, :D].float().cpu() - vh[0, key, :D]).abs().max().item() < 2e-2, (case, r)
+
+
 @pytest.mark.parametrize("D", [40, 64, 80])
 def test_attention_long_keys_fixed_reference_softmax(eng, D):
     """Key sequences >= 2048 take the fixed-reference softmax (the maximum is fixed after key tile 0, later tiles never look

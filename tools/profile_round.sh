@@ -36,8 +36,13 @@ for m in dit sdxl; do
     find $R/gpurun_out/prof_${TAG}_${m}_${name} -type f ! -name "*counter_collection.csv" -delete
   done
 done
+# sustained pass: the MFMA-busy / clock counters over 40 back-to-back steps (the held clock of a long run, not of the first seconds)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof_${TAG}_mfma40 -- python3 $R/bench.py --steps 40 --warmup 0 --no-cpu-baseline --no-profile > /dev/null 2> $R/gpurun_out/rocprof_${TAG}_mfma40.log; echo mfma40 rc=$?
+find $R/gpurun_out/prof_${TAG}_mfma40 -type f ! -name "*counter_collection.csv" -delete
 cd $R
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench_${TAG}.json 2> gpurun_out/bench_${TAG}.log; echo bench rc=$?
+# BASELINE config 2's size: 157 steps x 64 pairs = 10 048 pairs in one timed region (sustained clock)
+python3 bench.py --steps 157 --warmup 5 --no-cpu-baseline > gpurun_out/bench_${TAG}_10k.json 2> gpurun_out/bench_${TAG}_10k.log; echo bench10k rc=$?
 python3 bench.py --steps 20 --warmup 5 --streams 2 --no-cpu-baseline > gpurun_out/bench_${TAG}_two_streams.json 2> gpurun_out/bench_${TAG}_two_streams.log; echo two_streams rc=$?
 python3 bench.py --model sdxl --steps 6 --warmup 2 > gpurun_out/bench_${TAG}_sdxl.json 2> gpurun_out/bench_${TAG}_sdxl.log; echo sdxl rc=$?
 python3 bench.py --model dit --steps 10 --warmup 3 > gpurun_out/bench_${TAG}_dit.json 2> gpurun_out/bench_${TAG}_dit.log; echo dit rc=$?

@@ -574,20 +574,22 @@ int cu_count() {
 
 // Width (in tile columns) of the column bands the logical tile order walks (gemm_kernel setup()).  An XCD runs ~32 tiles at
 // a time; in row-major order at N = 10240 (40 tile columns) those are one activation panel x 32 different weight tiles,
-// 21 MB of weights against a 4 MiB L2: every tile re-fetched its whole weight tile over the fabric (7.3 GB per launch
+// 21 MB of weights against a 4 MiB L2: every tile re-fetched its whole weight tile over the fabric (7.1 GB per launch
 // measured for 1.1 GB algorithmic).  With bands of gn columns the concurrent set is (32 / gn) panels x gn weight tiles
 // and the band's weights (gn x BN x K) are re-used from L2 down the whole M sweep; the activations are then read
-// tilesN / gn times.  gn = the widest band whose weight tiles fit in about half the L2, at least 2 and at most 8.
-// Per-tile arithmetic is untouched: outputs are bit-identical for every gn.
+// tilesN / gn times (2.5-3.2 GB per launch at gn = 3..4: profiles/r04_experiments.txt item 1).  gn is 5 when five weight
+// tiles fit in ~2.5 MB of the L2, else 3: the ODD widths measured 2-5 % faster than 4 or 8 at equal or higher traffic (32
+// concurrent tiles are then not a whole number of panels, so an XCD's workgroups do not all sit on the same K offset of
+// the same lines).  Per-tile arithmetic is untouched: outputs are bit-identical for every gn.
 int gemm_band_width(int tilesM, int tilesN, size_t w_tile_bytes) {
     (void)tilesM;
     if (tilesN <= 4) return tilesN;                        // already one band (row-major order)
-    int gn = (int)((size_t)(2560 * 1024) / (w_tile_bytes ? w_tile_bytes : 1));
-    gn = gn < 2 ? 2 : (gn > 8 ? 8 : gn);
-    // even out the bands: N = 12 tile columns at gn = 5 -> 3 bands of 4, not 5 + 5 + 2
+    int gn = (size_t)5 * w_tile_bytes <= (size_t)2560 * 1024 ? 5 : 3;
+    // even out the bands: 12 tile columns at gn = 5 -> 3 bands of 4 ... but keep the width odd: 4 bands of 3
     const int bands = (tilesN + gn - 1) / gn;
-    gn = (tilesN + bands - 1) / bands;
-    return gn;
+    int even = (tilesN + bands - 1) / bands;
+    if (!(even & 1)) even = even > 3 ? even - 1 : 3;
+    return even < gn ? even : gn;
 }
 
 namespace {

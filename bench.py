@@ -43,7 +43,7 @@ TAP_KEYS_EXCLUDE = ("up_blocks.2", "up_blocks.3", "conv_norm_out", "conv_out")
 def rocprof_name(fam: str) -> str:
     p = fam.split("_")
     if p[0] == "gemm":
-        t = "__bf16" if p[1] == "bf16" else "float"
+        t = {"bf16": "__bf16", "f16": "_Float16"}.get(p[1], "float")
         bm, bn = p[2].split("x")
         mode = "1" if p[3] == "conv3" else "0"
         geglu = "true" if fam.endswith("_geglu") else "false"
@@ -258,7 +258,7 @@ def secondary(a, world, rank, dev):
     """Secondary bench lines: DiffSim-XL (SDXL U-Net, 1024 px, tap up_blocks [0,0,0]; BASELINE config 4) and
     DiffSim-DiT (DiT-XL/2, 256 px, tap blocks[13]; config 5, --fp8-attention) -- same step definition (latents resident
     in HBM -> scores), synthetic weights, same roofline / cpu_baseline fields as the headline line."""
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(a.dtype, torch.float32)
     bp = a.batch_pairs
     g = torch.Generator("cpu").manual_seed(1234 + rank)
     if a.model == "sdxl":
@@ -297,7 +297,7 @@ def secondary(a, world, rank, dev):
            "config": {"workload": name, "pairs_per_step_per_gpu": bp},
            "score_sample": [round(float(x), 6) for x in scores[:4].float().cpu()]}
     if rank == 0:
-        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_F32_TFLOPS if a.dtype == "fp32" else PEAK_BF16_TFLOPS         # fp16 MFMAs run at the bf16 rate
         if not a.no_profile:
             eng.profile(True)
             run()
@@ -371,7 +371,7 @@ def headline(a, world, rank, dev):
     from diffsim_amd.diffsim import DiffSim
     from diffsim_amd.engine import pair_score
     cfg = C.SD15
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(a.dtype, torch.float32)
     keys = [k for k in C.unet_param_shapes(cfg) if not k.startswith(TAP_KEYS_EXCLUDE)]
     sd = S.make_state_dict(cfg, seed=0, keys=keys)
     ds = DiffSim(torch_dtype=dtype, device=str(dev), unet_config=cfg, state_dict=sd, dedup_cfg=a.dedup_cfg, fusion=a.fusion)
@@ -442,7 +442,7 @@ def headline(a, world, rank, dev):
         "score_sample": [round(float(x), 6) for x in scores[:4].float().cpu()],
     }
     if rank == 0:
-        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_F32_TFLOPS if a.dtype == "fp32" else PEAK_BF16_TFLOPS         # fp16 MFMAs run at the bf16 rate
         if not a.no_profile:
             # ---- roofline of the dominant kernel: HIP events around every launch of one more step
             eng.profile(True)
@@ -474,7 +474,8 @@ def main():
                          "2 is ~2 %% faster (one sub-batch's norm kernels run under the other's GEMMs) and is what "
                          "DiffSim.score_latent_pairs does; the default stays 1 so that every kernel of the timed region runs alone on "
                          "the chip and its rocprofv3 duration is the kernel's own (the roofline leg divides by it)")
-    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--dtype", choices=["bf16", "fp16", "fp32"], default="bf16",
+                    help="compute dtype: bf16 = the headline (BASELINE config 2); fp16 = the reference drivers' torch.float16; fp32 = parity mode")
     ap.add_argument("--resident-batches", type=int, default=4,
                     help="distinct synthetic batches kept in HBM; the timed steps cycle through them")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -15,6 +15,9 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libdiffsim_amd.so")
 SOURCES = ["gemm.hip", "rowres.hip", "norm.hip", "attention.hip", "attention_fp8.hip", "pack.hip", "unet.hip", "vae.hip", "dit.hip"]
+# the kernel sources written against the 16-bit type h16 are compiled a second time with h16 = fp16 (csrc/common.h): the
+# compute dtype DSIM_F16, which the plain entry points forward to the *_f16 twins
+F16_SOURCES = ["gemm.hip", "rowres.hip", "norm.hip", "attention.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "store.h"), os.path.join(HERE, "..", "include", "diffsim_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -30,11 +33,12 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src: str) -> str:
-    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+def _compile(job) -> str:
+    src, f16 = job
+    obj = os.path.join(OBJ, src.replace(".hip", "_f16.o" if f16 else ".o"))
     path = os.path.join(CSRC, src)
     if _stale(obj, [path] + HEADERS):
-        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", path, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-DDSIM_H16_IS_F16"] if f16 else []) + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
@@ -43,8 +47,9 @@ def _compile(src: str) -> str:
 
 def build(verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
-        objs = list(ex.map(_compile, SOURCES))
+    jobs = [(src, False) for src in SOURCES] + [(src, True) for src in F16_SOURCES]
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        objs = list(ex.map(_compile, jobs))
     if _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -45,7 +45,8 @@ def build_parser() -> argparse.ArgumentParser:
                         "style_main.py (Sref / InstantStyle: one folder per style, 2000 sampled experiments)")
     p.add_argument("--experiments", type=int, default=2000, help="--dataset sref: sampled experiments (style_main.py:64)")
     p.add_argument("--model_path", type=str, default=None, help="diffusers-layout checkpoint directory (unet/, vae/, text_encoder/, tokenizer/)")
-    p.add_argument("--dtype", type=str, choices=["bf16", "fp32"], default="bf16", help="engine compute dtype (fp32 = parity mode)")
+    p.add_argument("--dtype", type=str, choices=["bf16", "fp16", "fp32"], default="bf16",
+                   help="engine compute dtype (fp16 = the reference drivers' torch.float16; fp32 = parity mode)")
     p.add_argument("--noise_dtype", type=str, choices=["fp32", "fp16"], default="fp32",
                    help="generator draws / add_noise arithmetic: fp32 pipeline or the reference's literal fp16 pipeline")
     p.add_argument("--batch", type=int, default=10, help="triplets per engine batch")

@@ -23,10 +23,10 @@
 //   - The softmax denominator comes out of the PV MFMAs: when the head dim leaves a spare column
 //     in the 32-wide d block (D = 40, 72, 80, 16) the staged V tile carries a column of ones, so
 //     row D of O^T accumulates sum(P) and is rescaled together with O.
-//   - V^T fragments come from the row-major V tile by ds_read_b64_tr_b16 (bf16) / ds_read_b32 (f32).
-//   - bf16: next tile's global loads are in flight during the current tile's compute (registers
+//   - V^T fragments come from the row-major V tile by ds_read_b64_tr_b16 (h16) / ds_read_b32 (f32).
+//   - h16: next tile's global loads are in flight during the current tile's compute (registers
 //     -> double-buffered LDS, one barrier per tile).  f32 parity mode: simple single buffer.
-// bf16 path: v_mfma_f32_32x32x16_bf16; fp32 parity path: v_mfma_f32_32x32x2_f32 (exact f32).
+// h16 path: v_mfma_f32_32x32x16_bf16; fp32 parity path: v_mfma_f32_32x32x2_f32 (exact f32).
 #include "common.h"
 
 namespace dsim {
@@ -49,14 +49,14 @@ template <typename T, int D> struct ACfg {
     static constexpr int NDB = (D + 31) / 32;     // 32-wide output blocks over d (PV)
     static constexpr int DPL = NDB * 32;          // LDS columns (zero padded)
     static constexpr bool ONES = D < DPL;         // spare column -> ones column gives the row sum
-    // K tile: only the NKS*16 columns QK^T reads (bf16); row stride an odd number of 16-B slots (ds_read_b128)
+    // K tile: only the NKS*16 columns QK^T reads (h16); row stride an odd number of 16-B slots (ds_read_b128)
     static constexpr int DPLK = (ES == 2) ? NKS * 16 : DPL;
     static constexpr int RS = DPLK * ES + 16;
-    // bf16, D = 8 (mod 16): K carries a ones column at d = D and Q carries -m there, so S^T comes out of the MFMAs
+    // h16, D = 8 (mod 16): K carries a ones column at d = D and Q carries -m there, so S^T comes out of the MFMAs
     // already relative to the running max and the accumulators start at the constant 0 (no per-tile register fill).
-    // Any per-row reference cancels in the softmax, so -m rounded to bf16 is exact as long as m itself is kept rounded.
+    // Any per-row reference cancels in the softmax, so -m rounded to h16 is exact as long as m itself is kept rounded.
     static constexpr bool KONE = (ES == 2) && (D % 16 == 8);
-    // V tile row stride.  bf16: the transposed reads (ds_read_b64_tr_b16) take, per 32-lane half, a
+    // V tile row stride.  h16: the transposed reads (ds_read_b64_tr_b16) take, per 32-lane half, a
     // 4-row x 32-column block = 4 rows x 16 dwords; they are conflict-free when the row stride is
     // 16 or 48 dwords mod 64 (four rows tile the 64 banks).  f32: plain ds_read_b32, same as K.
     static constexpr int RSV = (ES == 2) ? (((DPL * 2) % 256 == 64 || (DPL * 2) % 256 == 192) ? DPL * 2 : DPL * 2 + 64) : RS;
@@ -73,34 +73,34 @@ template <typename T, int D> struct ACfg {
 };
 
 struct FragF32 { f32x4 lo, hi; };
-template <typename T> struct FragOf { typedef bf16x8 type; };
+template <typename T> struct FragOf { typedef h16x8 type; };
 template <> struct FragOf<float> { typedef FragF32 type; };
 
-__device__ __forceinline__ void zero_frag(bf16x8& f) {
+__device__ __forceinline__ void zero_frag(h16x8& f) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = (bf16)0.0f;
+    for (int i = 0; i < 8; ++i) f[i] = (h16)0.0f;
 }
 __device__ __forceinline__ void zero_frag(FragF32& f) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) f.lo[i] = f.hi[i] = 0.f;
 }
 // load 8 consecutive elements and pre-scale them (Q only)
-__device__ __forceinline__ void gload_frag_scaled(bf16x8& f, const bf16* p, float sc) {
-    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+__device__ __forceinline__ void gload_frag_scaled(h16x8& f, const h16* p, float sc) {
+    const h16x8 t = *reinterpret_cast<const h16x8*>(p);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) f[i] = (bf16)((float)t[i] * sc);
+    for (int i = 0; i < 8; ++i) f[i] = (h16)((float)t[i] * sc);
 }
 __device__ __forceinline__ void gload_frag_scaled(FragF32& f, const float* p, float sc) {
     f.lo = *reinterpret_cast<const f32x4*>(p) * sc;
     f.hi = *reinterpret_cast<const f32x4*>(p + 4) * sc;
 }
-__device__ __forceinline__ void lload_frag(bf16x8& f, const char* p) { f = *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void lload_frag(h16x8& f, const char* p) { f = *reinterpret_cast<const h16x8*>(p); }
 __device__ __forceinline__ void lload_frag(FragF32& f, const char* p) {
     f.lo = *reinterpret_cast<const f32x4*>(p);
     f.hi = *reinterpret_cast<const f32x4*>(p + 16);
 }
-__device__ __forceinline__ void mma(const bf16x8& a, const bf16x8& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+__device__ __forceinline__ void mma(const h16x8& a, const h16x8& b, f32x16& c) {
+    c = H16_MFMA_32x32x16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ void mma(const FragF32& a, const FragF32& b, f32x16& c) {
 #pragma unroll
@@ -139,7 +139,7 @@ template <typename T, int D> struct StageRegs {
 };
 
 template <typename T> __device__ __forceinline__ u32x4 one_chunk();
-template <> __device__ __forceinline__ u32x4 one_chunk<bf16>() { u32x4 r = {0x00003F80u, 0u, 0u, 0u}; return r; }   // bf16 1.0 in element 0
+template <> __device__ __forceinline__ u32x4 one_chunk<h16>() { u32x4 r = {DSIM_H16_ONE_BITS, 0u, 0u, 0u}; return r; }   // 1.0 in element 0
 template <> __device__ __forceinline__ u32x4 one_chunk<float>() { u32x4 r = {0x3F800000u, 0u, 0u, 0u}; return r; }
 
 template <typename T, int D>
@@ -201,7 +201,7 @@ __device__ __forceinline__ void tile_store(char* lds, const StageRegs<T, D>& sr,
 // workgroup must call it together (it contains workgroup barriers).
 // FAST: the running maximum is fixed after key tile 0 -- the later tiles compute P = exp2(S - m) without looking at their
 // scores at all (no row maximum, no re-base test, no rescale: a third of the loop's non-exp vector instructions).  Softmax is
-// invariant to the reference point, so a row whose true maximum lies above m just carries P > 1 and larger sums (f32 / bf16
+// invariant to the reference point, so a row whose true maximum lies above m just carries P > 1 and larger sums (f32 / h16
 // have the exponent range for it).  Only if the excess passes ~100 (log2 units) can exp2 overflow; the caller detects that from a
 // non-finite or absurd denominator and re-runs the block with FAST = false (attend_checked).
 template <typename T, int D, bool FAST = false>
@@ -217,7 +217,7 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
     for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    float m_run = 0.f;          // running row max (log2 units); meaningful after tile 0 (KONE: a bf16 value)
+    float m_run = 0.f;          // running row max (log2 units); meaningful after tile 0 (KONE: a h16 value)
     f32x16 minit;               // the S^T accumulators' start value: -m_run (KONE: 0, the maximum rides in Q's spare slot)
 #pragma unroll
     for (int r = 0; r < 16; ++r) minit[r] = 0.f;
@@ -277,17 +277,17 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
         }
         // tmax is relative to m_run.  Tile 0 always re-bases; later tiles only when some row's max
         // grew (the running max settles after a few tiles) -- exact, not a threshold.
-        // (KONE re-bases only past a slack of 0.5, so that rounding m to bf16 cannot leave a row just above 0 and
+        // (KONE re-bases only past a slack of 0.5, so that rounding m to h16 cannot leave a row just above 0 and
         // re-trigger on every tile; P <= 1.42 there)
         constexpr float SLACK = C::KONE ? 0.5f : 0.f;
         if (kt == 0 || (!FAST && !__all(tmax <= SLACK))) {
             float delta = kt == 0 ? tmax : fmaxf(tmax, 0.f);
             if constexpr (C::KONE) {
                 if constexpr (sizeof(T) == 2) {
-                    const float m_new = (float)(bf16)(m_run + delta);      // the value Q can carry exactly
+                    const float m_new = (float)(h16)(m_run + delta);      // the value Q can carry exactly
                     delta = m_new - m_run;
                     m_run = m_new;
-                    if (half == 1) qf[C::NKS - 1][0] = (bf16)(-m_new);       // d = D lives in element 0 of the upper half
+                    if (half == 1) qf[C::NKS - 1][0] = (h16)(-m_new);       // d = D lives in element 0 of the upper half
                 }
             } else {
                 m_run += delta;
@@ -331,20 +331,19 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
             for (int jb = 0; jb < 2; ++jb) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    bf16x8 pf;
+                    h16x8 pf;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) pf[j] = (bf16)s[jb][8 * s2 + j];
+                    for (int j = 0; j < 8; ++j) pf[j] = (h16)s[jb][8 * s2 + j];
                     const char* vbase = vt + (jb * 32 + 16 * s2 + trow) * C::RSV + tcol * 2;
 #pragma unroll
                     for (int db = 0; db < C::NDB; ++db) {
                         const char* pa = vbase + db * 64;
-                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa));
-                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(pa + 8 * C::RSV));
-                        bf16x8 vf;
+                        h16x4 lo = h16_ds_read_tr16_b64((pa));
+                        h16x4 hi = h16_ds_read_tr16_b64((pa + 8 * C::RSV));
+                        h16x8 vf;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
-                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+                        o[db] = H16_MFMA_32x32x16(vf, pf, o[db], 0, 0, 0);
                     }
                 }
             }
@@ -385,7 +384,7 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
 
 // The fast form, checked: every row's denominator must be finite and sane (it is >= ~1 by construction: the row's own
 // tile-0 maximum contributes exp2(0)); otherwise some exp2 overflowed and the whole workgroup repeats the block exactly.
-// bf16 only (the fp32 parity mode keeps the exact running maximum).
+// h16 only (the fp32 parity mode keeps the exact running maximum).
 template <typename T, int D, bool FASTK>
 __device__ __forceinline__ void attend_checked(const QFrags<T, D>& qfr, const T* kb, const T* vb, int ldk, int Nk, char* lds,
                                                OAcc<T, D>& oacc) {
@@ -393,7 +392,7 @@ __device__ __forceinline__ void attend_checked(const QFrags<T, D>& qfr, const T*
         float l = 0.f;
         attend<T, D, true>(qfr, kb, vb, ldk, Nk, lds, oacc, &l);
         // workgroup-uniform decision (attend() contains workgroup barriers): any wave with a bad row sends everybody back
-        const int bad = !(l > 0.25f && l < 1e30f);
+        const int bad = !(l > 0.25f && l < DSIM_H16_LSUM_MAX);
         if (__syncthreads_or(bad)) attend<T, D, false>(qfr, kb, vb, ldk, Nk, lds, oacc);
     } else {
         attend<T, D, false>(qfr, kb, vb, ldk, Nk, lds, oacc);
@@ -411,12 +410,12 @@ __device__ __forceinline__ void attend_checked(const QFrags<T, D>& qfr, const T*
 // with the v_exp / v_cvt of unit n issued between the MFMAs (pinned by sched_barrier), so the matrix pipe executes while
 // the VALU converts.  The pipeline crosses tile borders (the last step of tile t starts tile t + 1's first QK and the first
 // step of tile t + 1 finishes tile t's last PV), so three K/V tiles are live: a 3-deep LDS ring (58 KB, two workgroups per
-// CU), one barrier per tile.  bf16, fixed-reference softmax (attend<.., FAST>: the maximum of key tile 0), Nk % 64 == 0.
+// CU), one barrier per tile.  h16, fixed-reference softmax (attend<.., FAST>: the maximum of key tile 0), Nk % 64 == 0.
 // DBG: kbench ablation masks (1 no v_exp, 2 no PV MFMAs, 4 no QK MFMAs, 8 no global loads in the loop, 16 no v_cvt); 0 in the product
 template <int D, int DBG = 0>
-__device__ __forceinline__ void attend_pipelined2(const QFrags<bf16, D> (&qfr)[2], const bf16* kb, const bf16* vb, int ldk, int Nk,
-                                                  char* lds0, OAcc<bf16, D> (&oacc)[2], float (&l_out)[2]) {
-    typedef bf16 T;
+__device__ __forceinline__ void attend_pipelined2(const QFrags<h16, D> (&qfr)[2], const h16* kb, const h16* vb, int ldk, int Nk,
+                                                  char* lds0, OAcc<h16, D> (&oacc)[2], float (&l_out)[2]) {
+    typedef h16 T;
     typedef ACfg<T, D> C;
     constexpr int BUF = 2 * C::TILE;                // one K tile + one V tile
     constexpr int NM = 2 * C::NDB + C::NKS;         // MFMAs per step
@@ -498,27 +497,27 @@ __device__ __forceinline__ void attend_pipelined2(const QFrags<bf16, D> (&qfr)[2
         s = minit[q];
 #pragma unroll
         for (int ks = 0; ks < C::NKS; ++ks) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(buf + koff + j * 32 * C::RS + ks * 32);
+            const h16x8 kf = *reinterpret_cast<const h16x8*>(buf + koff + j * 32 * C::RS + ks * 32);
             mma(kf, qloc[q].f[ks], s);
         }
     };
     auto vfrag = [&](const char* buf, int j, int s2, int db) {
         const char* pa = buf + voff + (j * 32 + 16 * s2) * C::RSV + db * 64;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa + 8 * C::RSV));
-        bf16x8 vf;
+        const h16x4 lo = h16_ds_read_tr16_b64((pa));
+        const h16x4 hi = h16_ds_read_tr16_b64((pa + 8 * C::RSV));
+        h16x8 vf;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
         return vf;
     };
-    auto pv = [&](const char* buf, int q, int j, const bf16x8 (&pf)[2]) {
+    auto pv = [&](const char* buf, int q, int j, const h16x8 (&pf)[2]) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int db = 0; db < C::NDB; ++db)
-                oacc[q].b[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag(buf, j, s2, db), pf[s2], oacc[q].b[db], 0, 0, 0);
+                oacc[q].b[db] = H16_MFMA_32x32x16(vfrag(buf, j, s2, db), pf[s2], oacc[q].b[db], 0, 0, 0);
     };
-    auto softmax = [&](int q, f32x16& s, bf16x8 (&pf)[2]) {
+    auto softmax = [&](int q, f32x16& s, h16x8 (&pf)[2]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
         if constexpr (!C::ONES) {
@@ -530,11 +529,11 @@ __device__ __forceinline__ void attend_pipelined2(const QFrags<bf16, D> (&qfr)[2
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pf[f][e] = (bf16)s[8 * f + e];
+            for (int e = 0; e < 8; ++e) pf[f][e] = (h16)s[8 * f + e];
     };
 
     // ---- key tile 0, unpipelined: it fixes every row's reference point -------------------------------------------------
-    bf16x8 pfA[2], pfB[2];
+    h16x8 pfA[2], pfB[2];
     f32x16 sA, sB;
     {
         f32x16 s0[2][2];
@@ -552,9 +551,9 @@ __device__ __forceinline__ void attend_pipelined2(const QFrags<bf16, D> (&qfr)[2
             tmax = max_halves(tmax);
             float delta = tmax;
             if constexpr (C::KONE) {
-                const float m_new = (float)(bf16)delta;            // the value Q's spare slot carries exactly
+                const float m_new = (float)(h16)delta;            // the value Q's spare slot carries exactly
                 delta = m_new;
-                if (half == 1) qloc[q].f[C::NKS - 1][0] = (bf16)(-m_new);
+                if (half == 1) qloc[q].f[C::NKS - 1][0] = (h16)(-m_new);
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) minit[q][r] = -delta;
@@ -564,7 +563,7 @@ __device__ __forceinline__ void attend_pipelined2(const QFrags<bf16, D> (&qfr)[2
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s0[q][j][r] -= delta;
         }
-        bf16x8 pft[2];
+        h16x8 pft[2];
         softmax(0, s0[0][0], pft); pv(lds0, 0, 0, pft);
         softmax(0, s0[0][1], pft); pv(lds0, 0, 1, pft);
         softmax(1, s0[1][0], pft); pv(lds0, 1, 0, pft);
@@ -573,14 +572,14 @@ __device__ __forceinline__ void attend_pipelined2(const QFrags<bf16, D> (&qfr)[2
     // The four steps of a tile need only two fragment sets: steps 1 and 2 share X = {V^T(t, j0), K(t, j1)}, step 3 and the
     // next tile's step 0 share Y = {V^T(t, j1), K(t + 1, j0)}.  Each is read from LDS ONE step before its first use (X during
     // step 0, Y during step 2), so no MFMA waits on an LDS round trip and every fragment read feeds two query blocks.
-    struct FragSet { bf16x8 vf[2][C::NDB]; bf16x8 kf[C::NKS]; };
+    struct FragSet { h16x8 vf[2][C::NDB]; h16x8 kf[C::NKS]; };
     auto load_set = [&](FragSet& F, const char* vbuf, int pj, const char* kbuf, int kj) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int db = 0; db < C::NDB; ++db) F.vf[s2][db] = vfrag(vbuf, pj, s2, db);
 #pragma unroll
-        for (int ks = 0; ks < C::NKS; ++ks) F.kf[ks] = *reinterpret_cast<const bf16x8*>(kbuf + koff + kj * 32 * C::RS + ks * 32);
+        for (int ks = 0; ks < C::NKS; ++ks) F.kf[ks] = *reinterpret_cast<const h16x8*>(kbuf + koff + kj * 32 * C::RS + ks * 32);
     };
     FragSet X, Y;
     // tile 1 becomes visible, tile 2 is on its way; the pipeline's first QK
@@ -594,7 +593,7 @@ __device__ __forceinline__ void attend_pipelined2(const QFrags<bf16, D> (&qfr)[2
 
     // One pipeline step: the MFMAs of PV(query block pq; P fragments pin; V^T fragments F.vf) and of QK(query block kq; F.kf)
     // -> sout, with the softmax of sin -> pout (a unit of query block sq) issued between them.
-    auto step = [&](const FragSet& F, int pq, const bf16x8 (&pin)[2], int kq, f32x16& sout, int sq, f32x16& sin, bf16x8 (&pout)[2]) {
+    auto step = [&](const FragSet& F, int pq, const h16x8 (&pin)[2], int kq, f32x16& sout, int sq, f32x16& sin, h16x8 (&pout)[2]) {
         __builtin_amdgcn_sched_barrier(0);
         constexpr int EPG = (DBG & 96) == 32 ? 4 : ((DBG & 96) == 64 ? 6 : ((DBG & 96) == 96 ? 8 : (16 + NM - 2) / (NM - 1)));       // v_exp per MFMA over the first NM - 1 groups
 #pragma unroll
@@ -603,12 +602,12 @@ __device__ __forceinline__ void attend_pipelined2(const QFrags<bf16, D> (&qfr)[2
             // PV reads were converted a QK group ago
             if (g >= C::NKS) {
                 const int s2 = (g - C::NKS) / C::NDB, db = (g - C::NKS) % C::NDB;
-                if (!(DBG & 2)) oacc[pq].b[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.vf[s2][db], pin[s2], oacc[pq].b[db], 0, 0, 0);
+                if (!(DBG & 2)) oacc[pq].b[db] = H16_MFMA_32x32x16(F.vf[s2][db], pin[s2], oacc[pq].b[db], 0, 0, 0);
             } else {
                 const int ks = g;
                 if (DBG & 4) { if (ks == 0) sout = minit[kq]; }
-                else if (ks == 0) sout = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.kf[0], qloc[kq].f[0], minit[kq], 0, 0, 0);
-                else sout = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F.kf[ks], qloc[kq].f[ks], sout, 0, 0, 0);
+                else if (ks == 0) sout = H16_MFMA_32x32x16(F.kf[0], qloc[kq].f[0], minit[kq], 0, 0, 0);
+                else sout = H16_MFMA_32x32x16(F.kf[ks], qloc[kq].f[ks], sout, 0, 0, 0);
             }
 #pragma unroll
             for (int r = g * EPG; r < (g + 1) * EPG && r < 16; ++r)
@@ -619,7 +618,7 @@ __device__ __forceinline__ void attend_pipelined2(const QFrags<bf16, D> (&qfr)[2
                 if ((g == (8 * f + 7) / EPG + 1) || (g == NM - 1 && (8 * f + 7) / EPG + 1 > NM - 1)) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        if (!(DBG & 16)) pout[f][e] = (bf16)sin[8 * f + e];
+                        if (!(DBG & 16)) pout[f][e] = (h16)sin[8 * f + e];
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -655,7 +654,7 @@ __device__ __forceinline__ void attend_pipelined2(const QFrags<bf16, D> (&qfr)[2
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db)
-            oacc[1].b[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y.vf[s2][db], pfB[s2], oacc[1].b[db], 0, 0, 0);
+            oacc[1].b[db] = H16_MFMA_32x32x16(Y.vf[s2][db], pfB[s2], oacc[1].b[db], 0, 0, 0);
     (void)bprev;
 
 #pragma unroll
@@ -683,7 +682,7 @@ __device__ __forceinline__ void attend_pipelined2(const QFrags<bf16, D> (&qfr)[2
 // grid ceil(Nq/256) * H * B (1-D): a workgroup = 4 waves x 64 query rows
 template <int D, int DBG>
 __global__ __launch_bounds__(256, 2) void attn_long_kernel(const AttnArgs p, const float scale_log2) {
-    typedef bf16 T;
+    typedef h16 T;
     typedef ACfg<T, D> C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
@@ -708,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void attn_long_kernel(const AttnArgs p, con
     float l[2];
     attend_pipelined2<D, DBG>(qf, (const T*)p.k + kvoff, (const T*)p.v + kvoff, p.ldk, p.Nk, smem, oa, l);
     // every row's denominator must be finite and sane (attend_checked): else the workgroup repeats the block exactly
-    const int bad = !(l[0] > 0.25f && l[0] < 1e30f) || !(l[1] > 0.25f && l[1] < 1e30f);
+    const int bad = !(l[0] > 0.25f && l[0] < DSIM_H16_LSUM_MAX) || !(l[1] > 0.25f && l[1] < DSIM_H16_LSUM_MAX);
     if (__syncthreads_or(bad)) {
         attend<T, D, false>(qf[0], (const T*)p.k + kvoff, (const T*)p.v + kvoff, p.ldk, p.Nk, smem, oa[0]);
         attend<T, D, false>(qf[1], (const T*)p.k + kvoff, (const T*)p.v + kvoff, p.ldk, p.Nk, smem, oa[1]);
@@ -723,10 +722,10 @@ __global__ __launch_bounds__(256, 2) void attn_long_kernel(const AttnArgs p, con
             for (int g = 0; g < 4; ++g) {
                 const int d = db * 32 + 8 * g + 4 * half;
                 if (d < D) {
-                    bf16x4 v4;
+                    h16x4 v4;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v4[j] = (bf16)oa[qb].b[db][4 * g + j];
-                    *reinterpret_cast<bf16x4*>(orow + d) = v4;
+                    for (int j = 0; j < 4; ++j) v4[j] = (h16)oa[qb].b[db][4 * g + j];
+                    *reinterpret_cast<h16x4*>(orow + d) = v4;
                 }
             }
     }
@@ -768,10 +767,10 @@ __global__ __launch_bounds__(256, (ACfg<T, D>::WPS)) void attn_kernel(const Attn
                 const int d = db * 32 + 8 * g + 4 * half;
                 if (d < D) {
                     if constexpr (sizeof(T) == 2) {
-                        bf16x4 v4;
+                        h16x4 v4;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v4[j] = (bf16)o[db][4 * g + j];
-                        *reinterpret_cast<bf16x4*>(orow + d) = v4;
+                        for (int j = 0; j < 4; ++j) v4[j] = (h16)o[db][4 * g + j];
+                        *reinterpret_cast<h16x4*>(orow + d) = v4;
                     } else {
                         f32x4 v4;
 #pragma unroll
@@ -789,12 +788,12 @@ __global__ __launch_bounds__(256, (ACfg<T, D>::WPS)) void attn_kernel(const Attn
 // 64 x 64 level (181 TF/s, 2.4 TB/s).  Here the keys (<= 96 = three 32-row blocks) are staged ONCE per workgroup and stay in
 // LDS while the workgroup walks QIT query blocks of its (batch, head) with no barrier in the loop: per block three S^T tiles,
 // ONE softmax pass with the exact row maximum (no running state), PV, normalise, store.  The launch becomes what its bytes say
-// it is: a stream of Q in and O out.  bf16; K / V images in attn_kernel's padded row-major layouts (ones column of V included).
+// it is: a stream of Q in and O out.  h16; K / V images in attn_kernel's padded row-major layouts (ones column of V included).
 // The heads of a token share cache lines in Q and O (80 bytes per head at d = 40): the XCD-aware block order that keeps the
 // heads of a batch element on one XCD matters more than anything inside the loop (0.62 -> 0.46 ms at d = 40).
 template <int D>
 __global__ __launch_bounds__(256, (D <= 80 ? 4 : 2)) void attn_short_kernel(const AttnArgs p, const float scale_log2, const int qit) {
-    typedef bf16 T;
+    typedef h16 T;
     typedef ACfg<T, D> C;
     constexpr int KR = 96;                                   // key rows held (three 32-row MFMA blocks)
     constexpr int CPRD = D / C::VEC;                         // real 16-byte chunks per row
@@ -853,7 +852,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 4 : 2)) void attn_short_kernel(cons
             for (int r = 0; r < 16; ++r) s[kbk][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < C::NKS; ++ks) {
-                bf16x8 kf;
+                h16x8 kf;
                 lload_frag(kf, kfr + kbk * 32 * C::RS + ks * 32);
                 mma(kf, qf.f[ks], s[kbk]);
             }
@@ -886,18 +885,18 @@ __global__ __launch_bounds__(256, (D <= 80 ? 4 : 2)) void attn_short_kernel(cons
         for (int kbk = 0; kbk < 3; ++kbk)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 pf;
+                h16x8 pf;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pf[e] = (bf16)s[kbk][8 * s2 + e];
+                for (int e = 0; e < 8; ++e) pf[e] = (h16)s[kbk][8 * s2 + e];
 #pragma unroll
                 for (int db = 0; db < C::NDB; ++db) {
                     const char* pa = vfr + (kbk * 32 + 16 * s2) * C::RSV + db * 64;
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(pa + 8 * C::RSV));
-                    bf16x8 vf;
+                    const h16x4 lo = h16_ds_read_tr16_b64((pa));
+                    const h16x4 hi = h16_ds_read_tr16_b64((pa + 8 * C::RSV));
+                    h16x8 vf;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+                    o[db] = H16_MFMA_32x32x16(vf, pf, o[db], 0, 0, 0);
                 }
             }
         float l_tot;
@@ -919,10 +918,10 @@ __global__ __launch_bounds__(256, (D <= 80 ? 4 : 2)) void attn_short_kernel(cons
                 for (int g = 0; g < 4; ++g) {
                     const int d = db * 32 + 8 * g + 4 * half;
                     if (d < D) {
-                        bf16x4 v4;
+                        h16x4 v4;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v4[e] = (bf16)(o[db][4 * g + e] * inv);
-                        *reinterpret_cast<bf16x4*>(orow + d) = v4;
+                        for (int e = 0; e < 4; ++e) v4[e] = (h16)(o[db][4 * g + e] * inv);
+                        *reinterpret_cast<h16x4*>(orow + d) = v4;
                     }
                 }
         }
@@ -1126,8 +1125,13 @@ int launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
     const int vec = dtype == DSIM_F32 ? 4 : 8;
     if (a.D % 8 || a.ldq % vec || a.ldk % vec || a.ldo % 4 || a.Nk < 1 || a.Nq < 1 || a.Bkv < 1)
         return DSIM_ERR_INVALID;
-    if (dtype == DSIM_BF16) return launch_attn_t<bf16>(a, s);
+    if (dtype == DSIM_H16) return launch_attn_t<h16>(a, s);
+#ifndef DSIM_H16_IS_F16
     if (dtype == DSIM_F32) return launch_attn_t<float>(a, s);
+#ifdef DSIM_HAS_F16_TWINS
+    if (dtype == DSIM_F16) return launch_attention_f16(a, dtype, s);
+#endif
+#endif
     return DSIM_ERR_INVALID;
 }
 
@@ -1142,8 +1146,14 @@ int launch_pair_score(const void* q, const void* k, const void* v, const int32_t
     if (n_pairs <= 0 || D % 8 || N < 1) return DSIM_ERR_INVALID;
     if (scratch_bytes < pair_score_scratch_bytes(n_pairs, B, H, N, D)) return DSIM_ERR_WORKSPACE;
     if (n_pairs * 2 > 65535) return DSIM_ERR_INVALID;
-    if (dtype == DSIM_BF16) return launch_tail_t<bf16>(q, k, v, ia, ib, n_pairs, B, H, N, D, similarity, out, scratch, s, status);
+    if (dtype == DSIM_H16) return launch_tail_t<h16>(q, k, v, ia, ib, n_pairs, B, H, N, D, similarity, out, scratch, s, status);
+#ifndef DSIM_H16_IS_F16
     if (dtype == DSIM_F32) return launch_tail_t<float>(q, k, v, ia, ib, n_pairs, B, H, N, D, similarity, out, scratch, s, status);
+#ifdef DSIM_HAS_F16_TWINS
+    if (dtype == DSIM_F16)
+        return launch_pair_score_f16(q, k, v, ia, ib, n_pairs, B, H, N, D, dtype, similarity, out, scratch, scratch_bytes, s, status);
+#endif
+#endif
     return DSIM_ERR_INVALID;
 }
 

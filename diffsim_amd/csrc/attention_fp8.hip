@@ -1,9 +1,9 @@
 // fp8 (OCP e4m3) MFMA attention for the DiT graph -- BASELINE.json config 5 ("DiffSim-DiT, fp8 MFMA attention").
 //
-// Same algorithm and tiling as attn_kernel<bf16, D> (attention.hip: a workgroup = 4 waves = 128 query rows of one
+// Same algorithm and tiling as attn_kernel<h16, D> (attention.hip: a workgroup = 4 waves = 128 query rows of one
 // (batch, head); swapped QK^T so that the softmax is lane-local; online softmax that re-bases only when a row max
 // grew; row sums from a ones row in V^T), with both matmuls on v_mfma_f32_32x32x16_fp8_fp8:
-//   * Q (pre-scaled by log2(e)/sqrt(D)), K and V arrive in bf16 and are rounded to e4m3 on the way into registers /
+//   * Q (pre-scaled by log2(e)/sqrt(D)), K and V arrive in h16 and are rounded to e4m3 on the way into registers /
 //     LDS (v_cvt_pk_fp8_f32, round-to-nearest-even, saturating).  No per-tensor scales: e4m3 is a floating format,
 //     a scale would move the range, not the 3-bit mantissa; |x| <= 448 holds for normalised activations.
 //   * P = exp2(s - m + 7): the accumulators start at -(m - 7), so the probabilities land in (0, 128] where e4m3 has
@@ -40,7 +40,7 @@ template <int D> struct F8Cfg {
     static constexpr int TILEV = DPL * RSV;
     static constexpr int TILE = (TILEK + TILEV + 15) & ~15;
     static constexpr int LDS = 2 * TILE;             // double buffered
-    static constexpr int CPRD = D / 8;               // 16-byte bf16 chunks per row
+    static constexpr int CPRD = D / 8;               // 16-byte h16 chunks per row
     static constexpr int NCH = (KT8 * CPRD + 255) / 256;
 };
 
@@ -50,9 +50,9 @@ __device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d
     r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
     return (unsigned)r;
 }
-// 8 bf16 (one 16-byte chunk) -> 8 fp8, optionally scaled
+// 8 h16 (one 16-byte chunk) -> 8 fp8, optionally scaled
 __device__ __forceinline__ long chunk_to_fp8(const u32x4& raw, float sc) {
-    const bf16x8 t = __builtin_bit_cast(bf16x8, raw);
+    const h16x8 t = __builtin_bit_cast(h16x8, raw);
     const unsigned lo = pack4_fp8((float)t[0] * sc, (float)t[1] * sc, (float)t[2] * sc, (float)t[3] * sc);
     const unsigned hi = pack4_fp8((float)t[4] * sc, (float)t[5] * sc, (float)t[6] * sc, (float)t[7] * sc);
     return (long)(((unsigned long)hi << 32) | lo);
@@ -80,10 +80,10 @@ __global__ __launch_bounds__(256, 2) void attn_fp8_kernel(const AttnArgs p, cons
     const int h = bh % p.H, b = bh / p.H;
     const int q = qblk * 128 + wave * 32 + l31;
     const int qc = q < p.Nq ? q : p.Nq - 1;
-    const bf16* qrow = (const bf16*)p.q + ((size_t)b * p.Nq + qc) * p.ldq + h * D;
+    const h16* qrow = (const h16*)p.q + ((size_t)b * p.Nq + qc) * p.ldq + h * D;
     const size_t kvoff = (size_t)(b % p.Bkv) * p.Nk * p.ldk + h * D;
-    const bf16* kb = (const bf16*)p.k + kvoff;
-    const bf16* vb = (const bf16*)p.v + kvoff;
+    const h16* kb = (const h16*)p.k + kvoff;
+    const h16* vb = (const h16*)p.v + kvoff;
     const int ldk = p.ldk, Nk = p.Nk;
 
     // Q fragments: 8 d-values at d = 16 ks + 8 half, pre-scaled, rounded to fp8
@@ -224,17 +224,17 @@ __global__ __launch_bounds__(256, 2) void attn_fp8_kernel(const AttnArgs p, cons
     const float other = __shfl_xor(mine, 32);
     const float inv = 1.0f / ((half == RH) ? mine : other);
     if (q < p.Nq) {
-        bf16* orow = (bf16*)p.out + ((size_t)b * p.Nq + q) * p.ldo + h * D;
+        h16* orow = (h16*)p.out + ((size_t)b * p.Nq + q) * p.ldo + h * D;
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d = db * 32 + 8 * g + 4 * half;
                 if (d < D) {
-                    bf16x4 v4;
+                    h16x4 v4;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v4[j] = (bf16)(o[db][4 * g + j] * inv);
-                    *reinterpret_cast<bf16x4*>(orow + d) = v4;
+                    for (int j = 0; j < 4; ++j) v4[j] = (h16)(o[db][4 * g + j] * inv);
+                    *reinterpret_cast<h16x4*>(orow + d) = v4;
                 }
             }
     }
@@ -254,7 +254,7 @@ int launch_f8(const AttnArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// bf16 q/k/v in, bf16 out; head dims of the DiT graphs: 72 (DiT-XL/2), 32 (test config)
+// h16 q/k/v in, h16 out; head dims of the DiT graphs: 72 (DiT-XL/2), 32 (test config)
 int launch_attention_fp8(const AttnArgs& a, hipStream_t s) {
     if (!a.q || !a.k || !a.v || !a.out || a.B < 1 || a.Bkv < 1 || a.H < 1 || a.Nq < 1 || a.Nk < 1) return DSIM_ERR_INVALID;
     if (a.ldq % 8 || a.ldk % 8 || a.ldo % 4) return DSIM_ERR_INVALID;

@@ -6,22 +6,79 @@
 
 #include "../../include/diffsim_amd.h"
 
+// ---- second compilation (h16 = fp16): the entry points of gemm / rowres / norm / attention .hip under an _f16 suffix ----------
+#ifdef DSIM_H16_IS_F16
+#define launch_gemm launch_gemm_f16
+#define gemm_tile_choice gemm_tile_choice_f16
+#define gemm_band_width gemm_band_width_f16
+#define cu_count cu_count_f16
+#define rowlin_stream_bytes rowlin_stream_bytes_f16
+#define pack_rowlin_stream pack_rowlin_stream_f16
+#define launch_rowlin launch_rowlin_f16
+#define groupnorm_scratch_bytes groupnorm_scratch_bytes_f16
+#define groupnorm_passes groupnorm_passes_f16
+#define launch_groupnorm launch_groupnorm_f16
+#define launch_layernorm launch_layernorm_f16
+#define launch_layernorm_mod launch_layernorm_mod_f16
+#define launch_softmax_rows launch_softmax_rows_f16
+#define launch_attention launch_attention_f16
+#define pair_score_scratch_bytes pair_score_scratch_bytes_f16
+#define launch_pair_score launch_pair_score_f16
+#define ff_stream_bytes ff_stream_bytes_f16
+#define pack_ff_stream pack_ff_stream_f16
+#define launch_ff_fused launch_ff_fused_f16
+#endif
+
 namespace dsim {
 
-typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// The 16-bit compute type.  The kernel sources (gemm / rowres / norm / attention .hip) are written against ONE 16-bit type,
+// h16, and are compiled twice (diffsim_amd/build.py): once with h16 = bf16 (compute dtype DSIM_BF16, the headline mode) and
+// once with -DDSIM_H16_IS_F16, h16 = IEEE fp16 (DSIM_F16: the arithmetic type the reference's drivers run in,
+// /root/reference/cute_main.py:31, diffsim/diffsim.py:82).  The fp16 objects carry the same entry points under an _f16
+// suffix (the #define block at the end of this header); the bf16 objects own the plain names and forward DSIM_F16 calls.
+// v_mfma_f32_16x16x32_f16 / v_mfma_f32_32x32x16_f16 take the same cycles as the bf16 forms, so tiles and schedules are shared.
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+#ifdef DSIM_H16_IS_F16
+typedef _Float16 h16;
+#define DSIM_H16 DSIM_F16
+#define DSIM_H16_ONE_BITS 0x3C00u
+// fixed-reference softmax (attention.hip attend<FAST>): P = exp2(s - m0) is stored in the 16-bit type; fp16 tops out at 65504, so
+// a row whose sum reaches 3e4 (a single P near the limit, or thousands of keys a few units above tile 0's maximum) takes the exact
+// running-maximum form instead (in bf16 the bound is the f32 exponent range)
+#define DSIM_H16_LSUM_MAX 3.0e4f
+#define H16_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define H16_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#else
+typedef __bf16 h16;
+#define DSIM_H16 DSIM_BF16
+#define DSIM_H16_ONE_BITS 0x3F80u
+#define DSIM_H16_LSUM_MAX 1e30f
+#define H16_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define H16_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
+typedef __attribute__((ext_vector_type(8))) h16 h16x8;
+typedef __attribute__((ext_vector_type(4))) h16 h16x4;
+typedef __attribute__((ext_vector_type(2))) h16 h16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #ifdef __HIPCC__
-// GELU (erf form, F.gelu's default) for bf16 outputs: x * sigmoid(x (a + b u + c u^2)), u = min(x^2, 64), with -log2(e) folded
-// into the constants (the clamp keeps the odd quintic monotone).  |error| <= 2.6e-5 absolute, <= 0.3 bf16 ulp of the result:
+// ds_read_b64_tr_b16 of the 16-bit compute type: p is a (generic) pointer into LDS
+__device__ __forceinline__ h16x4 h16_ds_read_tr16_b64(const char* p) {
+#ifdef DSIM_H16_IS_F16
+    typedef __fp16 fp16v4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    return __builtin_bit_cast(h16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16v4*)(p)));
+#else
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) h16x4*)(p));
+#endif
+}
+// GELU (erf form, F.gelu's default) for h16 outputs: x * sigmoid(x (a + b u + c u^2)), u = min(x^2, 64), with -log2(e) folded
+// into the constants (the clamp keeps the odd quintic monotone).  |error| <= 2.6e-5 absolute, <= 0.3 h16 ulp of the result:
 // one v_exp, one v_rcp and 7 plain VALU operations against 16 + 2 for the erf polynomial the fp32 parity mode keeps.  Used by
-// every bf16 GEGLU (the GEMM epilogue and the fused feed-forward), so the fused and unfused chains round alike.
+// every h16 GEGLU (the GEMM epilogue and the fused feed-forward), so the fused and unfused chains round alike.
 __device__ __forceinline__ float gelu_fast(float x) {
     const float u = fminf(x * x, 64.0f);
     const float t = x * fmaf(u, fmaf(u, 1.01426306e-3f, -0.106775724f), -2.30112134f);
@@ -96,7 +153,7 @@ constexpr int g_gemm_persistent = 1, g_force_bm = 0, g_gn_onepass = 1, g_ln_rows
 int gemm_band_width(int tilesM, int tilesN, size_t w_tile_bytes);   // tile-order band width (L2 reuse of the weight tiles)
 void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn);   // which template instantiation launch_gemm picks
 
-// weight repack kernels -- pack.hip  (src f32/bf16/f16 diffusers layout -> packed compute dtype)
+// weight repack kernels -- pack.hip  (src f32/h16/f16 diffusers layout -> packed compute dtype)
 int pack_linear(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int K,
                 int geglu_interleave, hipStream_t s);                       // [N][K] -> [N][K]
 int pack_conv3(const void* src, int src_dtype, void* dst, int dst_dtype, int Cout, int Cin,
@@ -104,7 +161,7 @@ int pack_conv3(const void* src, int src_dtype, void* dst, int dst_dtype, int Cou
 int pack_conv_in(const void* src, int src_dtype, float* dst, int Cout, int Cin, hipStream_t s);   // -> f32 [9*Ci][Co]
 int pack_vector(const void* src, int src_dtype, float* dst, int N, int geglu_interleave,
                 hipStream_t s);                                             // any -> f32
-// y[n] = bias[n] + sum_k W[n][k] * act(x[k]) ; all f32, W may be f32/bf16/f16 ; act: 0 id, 1 silu
+// y[n] = bias[n] + sum_k W[n][k] * act(x[k]) ; all f32, W may be f32/h16/f16 ; act: 0 id, 1 silu
 int gemv_f32(const void* W, int w_dtype, const void* bias, int b_dtype, const float* x, float* y,
              int N, int K, int act, hipStream_t s);
 int add_vectors_f32(const float* a, const float* b, float* out, int N, hipStream_t s);
@@ -122,16 +179,17 @@ int dup_batch(const void* in, void* out, int n_batch, size_t bytes_per_elem, hip
 
 // row-resident Linear for K = 320 (optionally behind a LayerNorm): out[M][N] = LN?(x) W^T (+ bias), N % 64 == 0, N <= 960 -- rowres.hip
 struct RowLinArgs {
-    const void* x = nullptr;                    // [M][C] bf16
-    void* out = nullptr;                        // [M][N] bf16
+    const void* x = nullptr;                    // [M][C] h16
+    void* out = nullptr;                        // [M][N] h16
     const float* ln_g = nullptr;                // null: no LayerNorm in front
     const float* ln_b = nullptr;
     const void* stream = nullptr;               // pack_rowlin_stream output
     int M = 0, C = 0, N = 0;
     float eps = 1e-5f;
+    int dtype = DSIM_BF16;                      // DSIM_BF16 or DSIM_F16
 };
 size_t rowlin_stream_bytes(int C, int N);       // 0: shape not covered
-int pack_rowlin_stream(const void* w_packed /*[N][C] bf16*/, void* stream, int C, int N, hipStream_t s);
+int pack_rowlin_stream(const void* w_packed /*[N][C] h16*/, void* stream, int C, int N, hipStream_t s);
 int launch_rowlin(const RowLinArgs& a, hipStream_t s);
 
 // uint8 HWC pixels -> process_image's normalised NCHW f32 (half: rounded through fp16); VAE posterior sample -- pack.hip
@@ -163,18 +221,18 @@ struct AttnArgs {
     int xcd_remap = 1;                        // 0: plain block order (micro-benchmark A/B only)
 };
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
-int launch_attention_fp8(const AttnArgs& a, hipStream_t s);      // bf16 in/out, e4m3 MFMAs (attention_fp8.hip)
+int launch_attention_fp8(const AttnArgs& a, hipStream_t s);      // h16 in/out, e4m3 MFMAs (attention_fp8.hip)
 size_t pair_score_scratch_bytes(int n_pairs, int B, int H, int N, int D);
 int launch_pair_score(const void* q, const void* k, const void* v, const int32_t* idx_a,
                       const int32_t* idx_b, int n_pairs, int B, int H, int N, int D, int dtype,
                       int similarity, float* out, void* scratch, size_t scratch_bytes, hipStream_t s,
                       int32_t* status = nullptr);
 
-// row-resident fused feed-forward of the 320-channel transformer blocks (bf16) -- rowres.hip
+// row-resident fused feed-forward of the 320-channel transformer blocks (h16) -- rowres.hip
 //   out = x + W2 (h * gelu(g)) + b2,  [h ; g] = W1 LN(x) + b1
 struct FFArgs {
-    const void* x = nullptr;                    // [M][C] bf16: LayerNorm input and residual
-    void* out = nullptr;                        // [M][C] bf16 (may alias x)
+    const void* x = nullptr;                    // [M][C] h16: LayerNorm input and residual
+    void* out = nullptr;                        // [M][C] h16 (may alias x)
     const float* ln_g = nullptr;
     const float* ln_b = nullptr;
     const void* stream = nullptr;               // pack_ff_stream output
@@ -182,11 +240,30 @@ struct FFArgs {
     const float* b2 = nullptr;                  // [C] f32
     int M = 0, C = 0;
     float eps = 1e-5f;
+    int dtype = DSIM_BF16;                      // DSIM_BF16 or DSIM_F16
 };
 size_t ff_stream_bytes(int C);                  // 0: no fused kernel for this width
-// w1_packed: the GEGLU-interleaved [8C][C] bf16 weight (pack_linear with geglu_interleave = 1); w2_packed: [C][4C] bf16
+// w1_packed: the GEGLU-interleaved [8C][C] h16 weight (pack_linear with geglu_interleave = 1); w2_packed: [C][4C] h16
 int pack_ff_stream(const void* w1_packed, const void* w2_packed, void* stream, int C, hipStream_t s);
 int launch_ff_fused(const FFArgs& a, hipStream_t s);
+
+#if !defined(DSIM_H16_IS_F16) && !defined(DSIM_DEVTOOLS)
+#define DSIM_HAS_F16_TWINS 1
+// the fp16 twins (same sources compiled with -DDSIM_H16_IS_F16); the plain entry points forward compute dtype DSIM_F16 to them
+int launch_gemm_f16(const GemmArgs& a, int dtype, hipStream_t s);
+int launch_rowlin_f16(const RowLinArgs& a, hipStream_t s);
+int launch_ff_fused_f16(const FFArgs& a, hipStream_t s);
+int launch_groupnorm_f16(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta, void* out, int B, int HW,
+                         int groups, float eps, int silu, int dtype, void* scratch, hipStream_t s);
+int launch_layernorm_f16(const void* x, const float* gamma, const float* beta, void* out, int M, int C, float eps, int dtype, hipStream_t s);
+int launch_layernorm_mod_f16(const void* x, const float* scale2, const float* shift2, void* out, int M, int C, int rows_per_batch, float eps,
+                             int dtype, hipStream_t s);
+int launch_softmax_rows_f16(const void* x, void* out, int rows, int cols, float scale, int dtype, hipStream_t s);
+int launch_attention_f16(const AttnArgs& a, int dtype, hipStream_t s);
+int launch_pair_score_f16(const void* q, const void* k, const void* v, const int32_t* idx_a, const int32_t* idx_b, int n_pairs, int B, int H,
+                          int N, int D, int dtype, int similarity, float* out, void* scratch, size_t scratch_bytes, hipStream_t s,
+                          int32_t* status);
+#endif
 
 // Per-device once-flags for hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count: the attribute is a
 // per-device property of the function, so a process that drives several devices must set it on each.

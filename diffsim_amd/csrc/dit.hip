@@ -119,7 +119,7 @@ struct DWalk {
         return st;
     }
     // per-launch HIP-event brackets of a profiled forward (same record format as the U-Net executor's)
-    const char* dtn() const { return h->dt == DSIM_F32 ? "f32" : "bf16"; }
+    const char* dtn() const { return h->dt == DSIM_F32 ? "f32" : (h->dt == DSIM_F16 ? "f16" : "bf16"); }
     void pbegin(const std::string& name, double flops, double bytes) {
         if (!run || !h->profiling) return;
         ProfRec r;
@@ -151,8 +151,11 @@ struct DWalk {
             const int K = c.in_channels * p * p;
             const dim3 grid((T + PE_TOK - 1) / PE_TOK, n);
             if (h->dt == DSIM_BF16)
-                hipLaunchKernelGGL(patch_embed_kernel<bf16>, grid, dim3(256), PE_TOK * K * sizeof(float), s, lat, noise, sa, sb,
-                                   (const float*)pw->p, (const float*)pb->p, (const float*)pos->p, (bf16*)x, c.in_channels, S, p, D);
+                hipLaunchKernelGGL(patch_embed_kernel<bf16_t>, grid, dim3(256), PE_TOK * K * sizeof(float), s, lat, noise, sa, sb,
+                                   (const float*)pw->p, (const float*)pb->p, (const float*)pos->p, (bf16_t*)x, c.in_channels, S, p, D);
+            else if (h->dt == DSIM_F16)
+                hipLaunchKernelGGL(patch_embed_kernel<f16_t>, grid, dim3(256), PE_TOK * K * sizeof(float), s, lat, noise, sa, sb,
+                                   (const float*)pw->p, (const float*)pb->p, (const float*)pos->p, (f16_t*)x, c.in_channels, S, p, D);
             else
                 hipLaunchKernelGGL(patch_embed_kernel<float>, grid, dim3(256), PE_TOK * K * sizeof(float), s, lat, noise, sa, sb,
                                    (const float*)pw->p, (const float*)pb->p, (const float*)pos->p, (float*)x, c.in_channels, S, p, D);
@@ -206,7 +209,7 @@ extern "C" {
 
 int dsim_dit_create(const dsim_dit_cfg* cfg, dsim_dit** out) {
     if (!cfg || !out) return DSIM_ERR_INVALID;
-    if (cfg->compute_dtype != DSIM_F32 && cfg->compute_dtype != DSIM_BF16) return DSIM_ERR_INVALID;
+    if (cfg->compute_dtype != DSIM_F32 && cfg->compute_dtype != DSIM_BF16 && cfg->compute_dtype != DSIM_F16) return DSIM_ERR_INVALID;
     if (cfg->tap_layer < 0 || cfg->tap_layer >= cfg->depth || cfg->hidden_size % cfg->num_heads ||
         cfg->input_size % cfg->patch_size)
         return DSIM_ERR_INVALID;

@@ -1,6 +1,6 @@
 // Implicit-GEMM MFMA kernel for gfx950: linear / 1x1 conv / 3x3 conv (stride 1|2, folded
 // nearest-2x upsample, channel-concat of two sources) with fused bias / residual / GEGLU
-// epilogues.  One template serves the bf16 production path (v_mfma_f32_16x16x32_bf16) and the
+// epilogues.  One template serves the h16 production path (v_mfma_f32_16x16x32_bf16) and the
 // fp32 parity path (v_mfma_f32_16x16x4_f32, an exact f32 fma chain).  The 16x16 shapes, not the 32x32 ones: at equal cycles
 // per FLOP the chip holds a ~12 % higher clock on them (MI355X_MICROARCH.md "DVFS give-back" item 7; measured here in the
 // regime of this K loop by tools/ubench_mfma_shape.hip: 1.94 against 1.74 GHz, 1855 against 1660 TF/s).
@@ -32,7 +32,7 @@ int g_gemm_persistent = 1;
 int g_gemm_exp = 0;
 #endif
 // Tile choice.  Small problems: 128-row tiles, 4 waves, two workgroups per CU (160-wide when N
-// allows -- every SD channel count is a multiple of 160 -- else 128).  bf16 problems with enough
+// allows -- every SD channel count is a multiple of 160 -- else 128).  h16 problems with enough
 // 256-row tiles to fill the chip: 256 x 320 (or 256 x 256, or 256 x 192 for the DiT widths) tiles, 8 waves as 4 x 2.
 void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn) {
     const bool geglu = a.epi == EPI_GEGLU;
@@ -68,7 +68,7 @@ void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn) {
 namespace {
 
 template <typename T> struct Traits;
-template <> struct Traits<bf16> {
+template <> struct Traits<h16> {
     static constexpr int BK = 64;     // elements per 128-byte LDS row
     static constexpr int VEC = 8;     // elements per 16-byte chunk
 };
@@ -78,15 +78,15 @@ template <> struct Traits<float> {
 };
 
 template <typename T> struct Vec16T;
-template <> struct Vec16T<bf16> { typedef bf16x8 type; };
+template <> struct Vec16T<h16> { typedef h16x8 type; };
 template <> struct Vec16T<float> { typedef f32x4 type; };
 
-// A fragment is 16 bytes per lane for both dtypes: lane (r = lane & 15, q = lane >> 4) holds elements k = 8q .. 8q+7 (bf16) or
+// A fragment is 16 bytes per lane for both dtypes: lane (r = lane & 15, q = lane >> 4) holds elements k = 8q .. 8q+7 (h16) or
 // k = 4q .. 4q+3 (f32) of row r of a 16-row block, i.e. 16-byte chunk q of the 64-byte K step.
-__device__ __forceinline__ void load_frag(bf16x8& f, const char* p) { f = *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void load_frag(h16x8& f, const char* p) { f = *reinterpret_cast<const h16x8*>(p); }
 __device__ __forceinline__ void load_frag(f32x4& f, const char* p) { f = *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void mma(const bf16x8& a, const bf16x8& b, f32x4& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+__device__ __forceinline__ void mma(const h16x8& a, const h16x8& b, f32x4& c) {
+    c = H16_MFMA_16x16x32(a, b, c, 0, 0, 0);
 }
 // f32: the 16-deep step is 4 exact-f32 MFMAs of depth 4; MFMA e takes element e of every lane, so lane quarter q supplies
 // k = 4q + e to both operands (any k pairing that is the same for A and B is a valid dot product).
@@ -94,7 +94,7 @@ __device__ __forceinline__ void mma(const f32x4& a, const f32x4& b, f32x4& c) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
 }
-template <typename T> struct FragOf { typedef bf16x8 type; };
+template <typename T> struct FragOf { typedef h16x8 type; };
 template <> struct FragOf<float> { typedef f32x4 type; };
 
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. f32 rounding level): one v_rcp, one
@@ -480,10 +480,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                 const int col = (GEGLU ? ((j >> 2) * 2 + (j & 1)) : j) * 16 + 4 * equad;
                 char* dst = wst + el15 * RSO + col * ES;
                 if constexpr (sizeof(T) == 2) {
-                    bf16x4 pk;
+                    h16x4 pk;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = (bf16)v[e];
-                    *reinterpret_cast<bf16x4*>(dst) = pk;
+                    for (int e = 0; e < 4; ++e) pk[e] = (h16)v[e];
+                    *reinterpret_cast<h16x4*>(dst) = pk;
                 } else {
                     f32x4 pk = {v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4*>(dst) = pk;
@@ -669,7 +669,7 @@ int launch_typed(const GemmArgs& a, hipStream_t s) {
     const bool big = bm == 256, n160 = bn == 160;
     (void)big;
     if constexpr (sizeof(T) == 2) {
-        // bf16, big problems: 256-row tiles, 8 waves as 4(M) x 2(N), 64-row x (BN/2)-column sub-tiles
+        // h16, big problems: 256-row tiles, 8 waves as 4(M) x 2(N), 64-row x (BN/2)-column sub-tiles
         if (big) {
             if (a.epi == EPI_GEGLU) return launch_one<T, 256, 256, GEMM_LINEAR, true, 4, 2>(a, s);
             if (a.mode == GEMM_CONV3) {
@@ -694,8 +694,13 @@ int launch_typed(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int launch_gemm(const GemmArgs& a, int dtype, hipStream_t s) {
-    if (dtype == DSIM_BF16) return launch_typed<bf16>(a, s);
+    if (dtype == DSIM_H16) return launch_typed<h16>(a, s);
+#ifndef DSIM_H16_IS_F16            // the fp16 objects hold the fp16 kernels only; the plain names forward DSIM_F16 to them
     if (dtype == DSIM_F32) return launch_typed<float>(a, s);
+#ifdef DSIM_HAS_F16_TWINS
+    if (dtype == DSIM_F16) return launch_gemm_f16(a, dtype, s);
+#endif
+#endif
     return DSIM_ERR_INVALID;
 }
 

@@ -33,7 +33,7 @@ __device__ __forceinline__ float silu_fast(float y) {
 }
 
 template <typename T> struct Vec16;
-template <> struct Vec16<bf16> { typedef bf16x8 type; static constexpr int N = 8; };
+template <> struct Vec16<h16> { typedef h16x8 type; static constexpr int N = 8; };
 template <> struct Vec16<float> { typedef f32x4 type; static constexpr int N = 4; };
 
 __host__ __device__ inline int gn_chunks(int HW) {
@@ -740,7 +740,7 @@ int gn_typed(const void* x0, int C0, const void* x1, int C1, const float* gamma,
 // passes over the tensor the GroupNorm of this shape makes (2 = one-pass form: read + write; 3 = statistics read + read + write)
 int groupnorm_passes(int C0, int C1, int HW, int groups, int dtype) {
     if (!g_gn_onepass) return 3;
-    const int cs = dtype == DSIM_F32 ? gn_onepass_slab<float>(C0, C1, 1, HW, groups) : gn_onepass_slab<bf16>(C0, C1, 1, HW, groups);
+    const int cs = dtype == DSIM_F32 ? gn_onepass_slab<float>(C0, C1, 1, HW, groups) : gn_onepass_slab<h16>(C0, C1, 1, HW, groups);   // (either 16-bit type)
     return cs ? 2 : 3;
 }
 
@@ -749,25 +749,41 @@ size_t groupnorm_scratch_bytes(int B, int groups) { return (size_t)B * 64 * grou
 int launch_groupnorm(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta,
                      void* out, int B, int HW, int groups, float eps, int silu, int dtype, void* scratch,
                      hipStream_t s) {
-    if (dtype == DSIM_BF16)
-        return gn_typed<bf16>(x0, C0, x1, C1, gamma, beta, out, B, HW, groups, eps, silu, scratch, s);
+    if (dtype == DSIM_H16)
+        return gn_typed<h16>(x0, C0, x1, C1, gamma, beta, out, B, HW, groups, eps, silu, scratch, s);
+#ifndef DSIM_H16_IS_F16
     if (dtype == DSIM_F32)
         return gn_typed<float>(x0, C0, x1, C1, gamma, beta, out, B, HW, groups, eps, silu, scratch, s);
+#ifdef DSIM_HAS_F16_TWINS
+    if (dtype == DSIM_F16)
+        return launch_groupnorm_f16(x0, C0, x1, C1, gamma, beta, out, B, HW, groups, eps, silu, dtype, scratch, s);
+#endif
+#endif
     return DSIM_ERR_INVALID;
 }
 
 int launch_layernorm(const void* x, const float* gamma, const float* beta, void* out, int M, int C, float eps,
                      int dtype, hipStream_t s) {
-    if (dtype == DSIM_BF16) return ln_typed<bf16, false>(x, gamma, beta, out, M, C, eps, 1, s);
+    if (dtype == DSIM_H16) return ln_typed<h16, false>(x, gamma, beta, out, M, C, eps, 1, s);
+#ifndef DSIM_H16_IS_F16
     if (dtype == DSIM_F32) return ln_typed<float, false>(x, gamma, beta, out, M, C, eps, 1, s);
+#ifdef DSIM_HAS_F16_TWINS
+    if (dtype == DSIM_F16) return launch_layernorm_f16(x, gamma, beta, out, M, C, eps, dtype, s);
+#endif
+#endif
     return DSIM_ERR_INVALID;
 }
 
 int launch_layernorm_mod(const void* x, const float* scale2, const float* shift2, void* out, int M, int C,
                          int rows_per_batch, float eps, int dtype, hipStream_t s) {
     if (rows_per_batch < 1) return DSIM_ERR_INVALID;
-    if (dtype == DSIM_BF16) return ln_typed<bf16, true>(x, scale2, shift2, out, M, C, eps, rows_per_batch, s);
+    if (dtype == DSIM_H16) return ln_typed<h16, true>(x, scale2, shift2, out, M, C, eps, rows_per_batch, s);
+#ifndef DSIM_H16_IS_F16
     if (dtype == DSIM_F32) return ln_typed<float, true>(x, scale2, shift2, out, M, C, eps, rows_per_batch, s);
+#ifdef DSIM_HAS_F16_TWINS
+    if (dtype == DSIM_F16) return launch_layernorm_mod_f16(x, scale2, shift2, out, M, C, rows_per_batch, eps, dtype, s);
+#endif
+#endif
     return DSIM_ERR_INVALID;
 }
 
@@ -775,10 +791,16 @@ int launch_softmax_rows(const void* x, void* out, int rows, int cols, float scal
     const int vec = dtype == DSIM_F32 ? 4 : 8;
     if (cols % vec || rows < 1) return DSIM_ERR_INVALID;
     const float sl2 = scale * 1.4426950408889634f;
-    if (dtype == DSIM_BF16)
-        hipLaunchKernelGGL(softmax_rows_kernel<bf16>, dim3(rows), dim3(256), 0, s, (const bf16*)x, (bf16*)out, cols, sl2);
+    if (dtype == DSIM_H16)
+        hipLaunchKernelGGL(softmax_rows_kernel<h16>, dim3(rows), dim3(256), 0, s, (const h16*)x, (h16*)out, cols, sl2);
+#ifndef DSIM_H16_IS_F16
     else if (dtype == DSIM_F32)
         hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3(rows), dim3(256), 0, s, (const float*)x, (float*)out, cols, sl2);
+#ifdef DSIM_HAS_F16_TWINS
+    else if (dtype == DSIM_F16)
+        return launch_softmax_rows_f16(x, out, rows, cols, scale, dtype, s);
+#endif
+#endif
     else
         return DSIM_ERR_INVALID;
     DSIM_HIP_CHECK(hipGetLastError());

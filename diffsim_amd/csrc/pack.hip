@@ -11,12 +11,13 @@ namespace {
 
 __device__ __forceinline__ float ld_any(const void* p, int dt, size_t i) {
     if (dt == DSIM_F32) return ((const float*)p)[i];
-    if (dt == DSIM_BF16) return (float)((const bf16*)p)[i];
+    if (dt == DSIM_BF16) return (float)((const bf16_t*)p)[i];
     return (float)((const _Float16*)p)[i];
 }
 __device__ __forceinline__ void st_any(void* p, int dt, size_t i, float v) {
     if (dt == DSIM_F32) ((float*)p)[i] = v;
-    else ((bf16*)p)[i] = (bf16)v;
+    else if (dt == DSIM_BF16) ((bf16_t*)p)[i] = (bf16_t)v;
+    else ((f16_t*)p)[i] = (f16_t)v;
 }
 
 // GEGLU row interleave: diffusers' ff.net.0.proj has rows [h (0..F) ; g (F..2F)].  The GEMM's
@@ -237,10 +238,11 @@ __global__ __launch_bounds__(256) void prep_conv_in8_kernel(const float* __restr
         for (int d = 0; d < dup; ++d) {
             T* o = out + ((size_t)(img * dup + d) * HW + pix) * Cout + co;
             if constexpr (sizeof(T) == 2) {
-                bf16x8 v;
+                typedef T Tx8 __attribute__((ext_vector_type(8)));          // bf16 or fp16
+                Tx8 v;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (bf16)acc[pp][e];
-                *reinterpret_cast<bf16x8*>(o) = v;
+                for (int e = 0; e < 8; ++e) v[e] = (T)acc[pp][e];
+                *reinterpret_cast<Tx8*>(o) = v;
             } else {
                 f32x4 v0 = {acc[pp][0], acc[pp][1], acc[pp][2], acc[pp][3]}, v1 = {acc[pp][4], acc[pp][5], acc[pp][6], acc[pp][7]};
                 *reinterpret_cast<f32x4*>(o) = v0;
@@ -311,7 +313,9 @@ int prep_conv_in(const float* lat, const float* noise, float sa, float sb, const
         const size_t lds8 = (size_t)PIX * 9 * Cin * sizeof(float);
         if (lds8 <= 48 * 1024) {
             if (dtype == DSIM_BF16)
-                hipLaunchKernelGGL((prep_conv_in8_kernel<bf16, PP>), grid8, dim3(256), lds8, st, lat, noise, sa, sb, w, bias, (bf16*)out, Cin, S, Cout, dup);
+                hipLaunchKernelGGL((prep_conv_in8_kernel<bf16_t, PP>), grid8, dim3(256), lds8, st, lat, noise, sa, sb, w, bias, (bf16_t*)out, Cin, S, Cout, dup);
+            else if (dtype == DSIM_F16)
+                hipLaunchKernelGGL((prep_conv_in8_kernel<f16_t, PP>), grid8, dim3(256), lds8, st, lat, noise, sa, sb, w, bias, (f16_t*)out, Cin, S, Cout, dup);
             else if (dtype == DSIM_F32)
                 hipLaunchKernelGGL((prep_conv_in8_kernel<float, PP>), grid8, dim3(256), lds8, st, lat, noise, sa, sb, w, bias, (float*)out, Cin, S, Cout, dup);
             else
@@ -323,7 +327,9 @@ int prep_conv_in(const float* lat, const float* noise, float sa, float sb, const
     const dim3 grid((S * S + PREP_PIX - 1) / PREP_PIX, n_img), block(256);
     const size_t lds = (size_t)PREP_PIX * 9 * Cin * sizeof(float);
     if (dtype == DSIM_BF16)
-        hipLaunchKernelGGL(prep_conv_in_kernel<bf16>, grid, block, lds, st, lat, noise, sa, sb, w, bias, (bf16*)out, Cin, S, Cout, dup);
+        hipLaunchKernelGGL(prep_conv_in_kernel<bf16_t>, grid, block, lds, st, lat, noise, sa, sb, w, bias, (bf16_t*)out, Cin, S, Cout, dup);
+    else if (dtype == DSIM_F16)
+        hipLaunchKernelGGL(prep_conv_in_kernel<f16_t>, grid, block, lds, st, lat, noise, sa, sb, w, bias, (f16_t*)out, Cin, S, Cout, dup);
     else if (dtype == DSIM_F32)
         hipLaunchKernelGGL(prep_conv_in_kernel<float>, grid, block, lds, st, lat, noise, sa, sb, w, bias, (float*)out, Cin, S, Cout, dup);
     else

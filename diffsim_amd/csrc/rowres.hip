@@ -1,4 +1,4 @@
-// Row-resident transformer kernels for the 320-channel (64 x 64) level of the SD U-Net, gfx950, bf16.
+// Row-resident transformer kernels for the 320-channel (64 x 64) level of the SD U-Net, gfx950, h16.
 //
 // The BasicTransformerBlock's feed-forward at C = 320 -- LayerNorm -> Linear(C, 8C) -> h * gelu(g) -> Linear(4C, C) ->
 // + residual (control flow: /root/reference/diffsim/hacked_modules.py:82-132, the diffusers FeedForward / GEGLU modules
@@ -19,8 +19,8 @@
 //     chunk it-1 and GEMM2(it-2): three independent register sets, so the GELU's VALU instructions and the ring's DMA
 //     issues sit in the shadow of 60 MFMAs (<= 4 single-issue fillers per MFMA: MI355X_MICROARCH.md, "HIDDEN per gap").
 //   * Epilogue: + b2 (accumulator init), D^T -> row-major through a wave-private LDS slab, + residual, 16-byte stores.
-// The bf16 GELU here is x * sigmoid(x (a + b u + c u^2)), u = min(x^2, 64): |err| <= 2.6e-5 absolute against the erf form
-// (bf16 resolution at 1.0 is 3.9e-3); the fp32 parity mode never takes this path.
+// The h16 GELU here is x * sigmoid(x (a + b u + c u^2)), u = min(x^2, 64): |err| <= 2.6e-5 absolute against the erf form
+// (h16 resolution at 1.0 is 3.9e-3); the fp32 parity mode never takes this path.
 #include "common.h"
 
 namespace dsim {
@@ -38,12 +38,12 @@ constexpr int RPIECES = RCHB / 1024;          // 60 LDS-DMA pieces: 15 per wave,
 constexpr int RPW = RPIECES / 4;
 // resident vectors (f32): b1 [8C] GEGLU-interleaved, b2 [C], LayerNorm gamma / beta [C]
 constexpr int RB1 = 0, RB2 = 8 * RC, RLG = 9 * RC, RLB = 10 * RC, RVEC = 11 * RC;
-constexpr int RSCR = 32 * 144;                // per-wave transpose slab: 32 rows x (64 cols bf16 + 16 pad)
+constexpr int RSCR = 32 * 144;                // per-wave transpose slab: 32 rows x (64 cols h16 + 16 pad)
 constexpr int RLDS = 2 * RCHB + RVEC * 4 + 4 * RSCR;     // 155392
 static_assert(RPIECES % 4 == 0 && RITER % 2 == 0, "ring geometry");
 
 // stream chunk ci, 16-byte unit u: see the layout comment at the top
-__global__ void pack_ff_stream_kernel(const bf16* __restrict__ w1p, const bf16* __restrict__ w2p, char* __restrict__ stream) {
+__global__ void pack_ff_stream_kernel(const h16* __restrict__ w1p, const h16* __restrict__ w2p, char* __restrict__ stream) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= RITER * (RCHB / 16)) return;
     const int ci = i / (RCHB / 16), o = (i - ci * (RCHB / 16)) * 16;
@@ -60,7 +60,7 @@ __global__ void pack_ff_stream_kernel(const bf16* __restrict__ w1p, const bf16* 
             const int row = o2 / 64, cpos = (o2 % 64) / 16;
             const int cl = cpos ^ ((row >> 2) & 3);
             const int s = cl >> 1, hh = cl & 1;
-            bf16x8 e;
+            h16x8 e;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 e[j] = w2p[(size_t)row * (4 * RC) + 32 * c + 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)];
@@ -71,8 +71,8 @@ __global__ void pack_ff_stream_kernel(const bf16* __restrict__ w1p, const bf16* 
 }
 
 struct FFParams {
-    const bf16* x;          // [M][320] residual stream (input of the LayerNorm and the residual)
-    bf16* out;              // [M][320]; may alias x
+    const h16* x;          // [M][320] residual stream (input of the LayerNorm and the residual)
+    h16* out;              // [M][320]; may alias x
     const float* ln_g;
     const float* ln_b;
     const char* stream;     // RITER * RCHB bytes
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FFParams p, cons
 #pragma unroll
     for (int s = 0; s < 2; ++s) w2off[s] = RW1B + l31 * 64 + (((2 * s + half) ^ sw2) << 4);
 
-    // rows of a tile as raw bf16 B-operand fragments: lane (l31, half) holds columns 16 ks + 8 half .. + 7 of row l31
+    // rows of a tile as raw h16 B-operand fragments: lane (l31, half) holds columns 16 ks + 8 half .. + 7 of row l31
     u32x4 raw[RKS];
     auto load_rows = [&](int tile) {
         const int row = tile * 128 + wave * 32 + l31;
@@ -138,14 +138,14 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FFParams p, cons
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * 128 + wave * 32;
         // ---- LayerNorm in registers -> B-operand fragments ---------------------------------------
-        // three passes over the bf16 registers (sum, centred squares, normalise): an f32 copy of the rows would not fit
+        // three passes over the h16 registers (sum, centred squares, normalise): an f32 copy of the rows would not fit
         // beside them in the 256 architectural VGPRs the VALU can address
-        bf16x8 X[RKS];
+        h16x8 X[RKS];
         {
             float sum = 0.f;
 #pragma unroll
             for (int ks = 0; ks < RKS; ++ks) {
-                const bf16x8 t = __builtin_bit_cast(bf16x8, raw[ks]);
+                const h16x8 t = __builtin_bit_cast(h16x8, raw[ks]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) sum += (float)t[j];
             }
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FFParams p, cons
 #pragma unroll
             for (int ks = 0; ks < RKS; ++ks) {
                 asm volatile("" : "+v"(raw[ks]));      // (opaque: keeps hipcc from carrying the f32 conversions from pass to pass)
-                const bf16x8 t = __builtin_bit_cast(bf16x8, raw[ks]);
+                const h16x8 t = __builtin_bit_cast(h16x8, raw[ks]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float d = (float)t[j] - mean; sq = fmaf(d, d, sq); }
             }
@@ -175,11 +175,11 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FFParams p, cons
                 const f32x4 g0 = *reinterpret_cast<const f32x4*>(vec + RLG + c), g1 = *reinterpret_cast<const f32x4*>(vec + RLG + c + 4);
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(vec + RLB + c), b1 = *reinterpret_cast<const f32x4*>(vec + RLB + c + 4);
                 asm volatile("" : "+v"(raw[ks]));
-                const bf16x8 t = __builtin_bit_cast(bf16x8, raw[ks]);
+                const h16x8 t = __builtin_bit_cast(h16x8, raw[ks]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    X[ks][j] = (bf16)fmaf(((float)t[j] - mean) * rstd, g0[j], b0[j]);
-                    X[ks][4 + j] = (bf16)fmaf(((float)t[4 + j] - mean) * rstd, g1[j], b1[j]);
+                    X[ks][j] = (h16)fmaf(((float)t[j] - mean) * rstd, g0[j], b0[j]);
+                    X[ks][4 + j] = (h16)fmaf(((float)t[4 + j] - mean) * rstd, g1[j], b1[j]);
                 }
             }
         }
@@ -197,9 +197,9 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FFParams p, cons
         __builtin_amdgcn_sched_barrier(0);
 
         f32x16 aH[2], aG[2];      // GEMM1 accumulator sets (chunk parity)
-        bf16x8 wf[2][4];          // double-buffered weight fragments: group n reads set n & 1 while set (n + 1) & 1 loads
-        bf16x8 p0, p1;            // h * gelu(g) of chunk it-2: the two k-steps of GEMM2's B operand
-        bf16x8 q0, q1;            // ... of chunk it-1, being produced
+        h16x8 wf[2][4];          // double-buffered weight fragments: group n reads set n & 1 while set (n + 1) & 1 loads
+        h16x8 p0, p1;            // h * gelu(g) of chunk it-2: the two k-steps of GEMM2's B operand
+        h16x8 q0, q1;            // ... of chunk it-1, being produced
         float hv[16];
 
         // wave w idles w * stagger units after each ring barrier: the loop lives inside one asm statement, so hipcc's
@@ -220,47 +220,47 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FFParams p, cons
             }
         };
         // GEMM1 group i = k-steps 2i, 2i+1: fragments [h(2i), g(2i), h(2i+1), g(2i+1)]
-        auto ld1 = [&](const char* slot, int i, bf16x8 (&w)[4]) {
+        auto ld1 = [&](const char* slot, int i, h16x8 (&w)[4]) {
             if ((DBG & 16) && i > 0) return;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int ks = 2 * i + u;
                 const char* a = slot + (ks >> 2) * 8192 + w1off[ks & 3];
-                w[2 * u] = *reinterpret_cast<const bf16x8*>(a);
-                w[2 * u + 1] = *reinterpret_cast<const bf16x8*>(a + 32 * 128);
+                w[2 * u] = *reinterpret_cast<const h16x8*>(a);
+                w[2 * u + 1] = *reinterpret_cast<const h16x8*>(a + 32 * 128);
             }
         };
-        auto mm1 = [&](int i, const bf16x8 (&w)[4], f32x16& h, f32x16& gg) {
+        auto mm1 = [&](int i, const h16x8 (&w)[4], f32x16& h, f32x16& gg) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (DBG & 4) { asm volatile("" :: "v"(w[2 * u]), "v"(w[2 * u + 1]), "v"(X[2 * i + u])); continue; }
-                h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2 * u], X[2 * i + u], h, 0, 0, 0);
-                gg = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2 * u + 1], X[2 * i + u], gg, 0, 0, 0);
+                h = H16_MFMA_32x32x16(w[2 * u], X[2 * i + u], h, 0, 0, 0);
+                gg = H16_MFMA_32x32x16(w[2 * u + 1], X[2 * i + u], gg, 0, 0, 0);
             }
         };
         // GEMM2 group j = output blocks 2j, 2j+1: fragments [b(2j) s0, b(2j) s1, b(2j+1) s0, b(2j+1) s1]
-        auto ld2 = [&](const char* slot, int j, bf16x8 (&w)[4]) {
+        auto ld2 = [&](const char* slot, int j, h16x8 (&w)[4]) {
             if (DBG & 16) return;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                w[2 * u] = *reinterpret_cast<const bf16x8*>(slot + w2off[0] + (2 * j + u) * 2048);
-                w[2 * u + 1] = *reinterpret_cast<const bf16x8*>(slot + w2off[1] + (2 * j + u) * 2048);
+                w[2 * u] = *reinterpret_cast<const h16x8*>(slot + w2off[0] + (2 * j + u) * 2048);
+                w[2 * u + 1] = *reinterpret_cast<const h16x8*>(slot + w2off[1] + (2 * j + u) * 2048);
             }
         };
-        auto mm2 = [&](int j, const bf16x8 (&w)[4]) {
+        auto mm2 = [&](int j, const h16x8 (&w)[4]) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (DBG & 8) { asm volatile("" :: "v"(w[2 * u]), "v"(w[2 * u + 1]), "v"(p0), "v"(p1)); continue; }
-                out[2 * j + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2 * u], p0, out[2 * j + u], 0, 0, 0);
-                out[2 * j + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2 * u + 1], p1, out[2 * j + u], 0, 0, 0);
+                out[2 * j + u] = H16_MFMA_32x32x16(w[2 * u], p0, out[2 * j + u], 0, 0, 0);
+                out[2 * j + u] = H16_MFMA_32x32x16(w[2 * u + 1], p1, out[2 * j + u], 0, 0, 0);
             }
         };
         // element e of h * gelu(g) of the previous chunk; pairs are packed as soon as the odd one exists
         auto geglu1 = [&](int e, const f32x16& h, const f32x16& gg) {
             hv[e] = (DBG & 2) ? h[e] + gg[e] : h[e] * gelu_fast(gg[e]);
             if (e & 1) {
-                if (e < 8) { q0[e - 1] = (bf16)hv[e - 1]; q0[e] = (bf16)hv[e]; }
-                else { q1[e - 9] = (bf16)hv[e - 1]; q1[e - 8] = (bf16)hv[e]; }
+                if (e < 8) { q0[e - 1] = (h16)hv[e - 1]; q0[e] = (h16)hv[e]; }
+                else { q1[e - 9] = (h16)hv[e - 1]; q1[e - 8] = (h16)hv[e]; }
             }
         };
         // One iteration, pinned group by group (left alone hipcc issues every ds_read right before its MFMA, and a lone wave
@@ -330,20 +330,20 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FFParams p, cons
             for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    bf16x4 pk;
+                    h16x4 pk;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = (bf16)out[2 * pp + bb][4 * q + e];
-                    *reinterpret_cast<bf16x4*>(slab + l31 * 144 + (bb * 32 + 8 * q + 4 * half) * 2) = pk;
+                    for (int e = 0; e < 4; ++e) pk[e] = (h16)out[2 * pp + bb][4 * q + e];
+                    *reinterpret_cast<h16x4*>(slab + l31 * 144 + (bb * 32 + 8 * q + 4 * half) * 2) = pk;
                 }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int idx = lane + it * 64, r = idx >> 3, c = idx & 7;
                 const unsigned go = (m0 + r) < p.M ? (unsigned)(m0 + r) * (RC * 2) + (unsigned)(pp * 128 + c * 16) : OOB;
-                const bf16x8 t = *reinterpret_cast<const bf16x8*>(slab + r * 144 + c * 16);
-                const bf16x8 rr = __builtin_bit_cast(bf16x8, res[pp][it]);
-                bf16x8 o;
+                const h16x8 t = *reinterpret_cast<const h16x8*>(slab + r * 144 + c * 16);
+                const h16x8 rr = __builtin_bit_cast(h16x8, res[pp][it]);
+                h16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)t[e] + (float)rr[e]);
+                for (int e = 0; e < 8; ++e) o[e] = (h16)((float)t[e] + (float)rr[e]);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rO, (int)go, 0, 0);
             }
         }
@@ -363,10 +363,10 @@ __global__ __launch_bounds__(256, 1) void ff_fused_kernel(const FFParams p, cons
 constexpr int LCHB = 32 * RC * 2;              // 20480 bytes per ring slot: W rows [32 b, 32 b + 32) x K 320, five [32][128 B] slabs
 constexpr int LPW = LCHB / 1024 / 4;           // 5 DMA pieces per wave per block
 constexpr int LVEC = 2 * RC;                   // resident f32: LayerNorm gamma, beta
-constexpr int LSCR = 16 * 144;                 // per-wave transpose slab: 16 rows x (64 cols bf16 + 16 pad)
+constexpr int LSCR = 16 * 144;                 // per-wave transpose slab: 16 rows x (64 cols h16 + 16 pad)
 constexpr int LLDS = 2 * LCHB + LVEC * 4 + 4 * LSCR;      // 52736: three workgroups per CU
 
-__global__ void pack_rowlin_stream_kernel(const bf16* __restrict__ wp, char* __restrict__ stream, int N) {
+__global__ void pack_rowlin_stream_kernel(const h16* __restrict__ wp, char* __restrict__ stream, int N) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N / 32 * (LCHB / 16)) return;
     const int b = i / (LCHB / 16), o = (i - b * (LCHB / 16)) * 16;
@@ -377,8 +377,8 @@ __global__ void pack_rowlin_stream_kernel(const bf16* __restrict__ wp, char* __r
 }
 
 struct RLParams {
-    const bf16* x;
-    bf16* out;
+    const h16* x;
+    h16* out;
     const float* ln_g;      // null: no LayerNorm
     const float* ln_b;
     const char* stream;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256, 3) void rowlin_kernel(const RLParams p, const 
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * 128 + wave * 32;
-        // the rows live in ONE register array: raw bf16 on arrival, overwritten in place by their normalised values
+        // the rows live in ONE register array: raw h16 on arrival, overwritten in place by their normalised values
         u32x4 xr[RKS];
         {
             const int row = m0 + l31;
@@ -426,11 +426,11 @@ __global__ __launch_bounds__(256, 3) void rowlin_kernel(const RLParams p, const 
 #pragma unroll
             for (int ks = 0; ks < RKS; ++ks)
                 xr[ks] = (DBG & 4) ? u32x4{(unsigned)ks, 1u, 2u, rbase} : __builtin_amdgcn_raw_buffer_load_b128(rX, (int)(rbase + ks * 32), 0, 0);
-            if (p.ln_g) {                       // the LayerNorm of ff_fused_kernel (three passes over the bf16 registers)
+            if (p.ln_g) {                       // the LayerNorm of ff_fused_kernel (three passes over the h16 registers)
                 float sum = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < RKS; ++ks) {
-                    const bf16x8 t = __builtin_bit_cast(bf16x8, xr[ks]);
+                    const h16x8 t = __builtin_bit_cast(h16x8, xr[ks]);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) sum += (float)t[j];
                 }
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256, 3) void rowlin_kernel(const RLParams p, const 
 #pragma unroll
                 for (int ks = 0; ks < RKS; ++ks) {
                     asm volatile("" : "+v"(xr[ks]));
-                    const bf16x8 t = __builtin_bit_cast(bf16x8, xr[ks]);
+                    const h16x8 t = __builtin_bit_cast(h16x8, xr[ks]);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { const float d = (float)t[j] - mean; sq = fmaf(d, d, sq); }
                 }
@@ -460,12 +460,12 @@ __global__ __launch_bounds__(256, 3) void rowlin_kernel(const RLParams p, const 
                     const f32x4 g0 = *reinterpret_cast<const f32x4*>(vec + c), g1 = *reinterpret_cast<const f32x4*>(vec + c + 4);
                     const f32x4 b0 = *reinterpret_cast<const f32x4*>(vec + RC + c), b1 = *reinterpret_cast<const f32x4*>(vec + RC + c + 4);
                     asm volatile("" : "+v"(xr[ks]));
-                    const bf16x8 t = __builtin_bit_cast(bf16x8, xr[ks]);
-                    bf16x8 y;
+                    const h16x8 t = __builtin_bit_cast(h16x8, xr[ks]);
+                    h16x8 y;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        y[j] = (bf16)fmaf(((float)t[j] - mean) * rstd, g0[j], b0[j]);
-                        y[4 + j] = (bf16)fmaf(((float)t[4 + j] - mean) * rstd, g1[j], b1[j]);
+                        y[j] = (h16)fmaf(((float)t[j] - mean) * rstd, g0[j], b0[j]);
+                        y[4 + j] = (h16)fmaf(((float)t[4 + j] - mean) * rstd, g1[j], b1[j]);
                     }
                     xr[ks] = __builtin_bit_cast(u32x4, y);
                     __builtin_amdgcn_sched_barrier(0);
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256, 3) void rowlin_kernel(const RLParams p, const 
         }
         __builtin_amdgcn_sched_barrier(0);
         // one ring step: the 20 MFMAs of weight block `blk` (32 output columns) into `a`, fragments double-buffered by 64-wide K slab
-        bf16x8 wf[2][2];
+        h16x8 wf[2][2];
         auto step = [&](int sp, f32x16& a) {
             // the slot's five DMA pieces must have landed; the four row-segment stores of the previous pair were issued after the
             // pieces of an even step (vmcnt retires in issue order on gfx9): leave them in flight there
@@ -487,11 +487,11 @@ __global__ __launch_bounds__(256, 3) void rowlin_kernel(const RLParams p, const 
             const char* slot = smem + sp * LCHB;
 #pragma unroll
             for (int e = 0; e < 16; ++e) a[e] = 0.f;
-            auto ld = [&](int i, bf16x8 (&w)[2]) {
+            auto ld = [&](int i, h16x8 (&w)[2]) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int ks = 2 * i + u;
-                    w[u] = *reinterpret_cast<const bf16x8*>(slot + (ks >> 2) * 4096 + woff[ks & 3]);
+                    w[u] = *reinterpret_cast<const h16x8*>(slot + (ks >> 2) * 4096 + woff[ks & 3]);
                 }
             };
             ld(0, wf[0]);
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256, 3) void rowlin_kernel(const RLParams p, const 
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
-                    if (!(DBG & 2)) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i & 1][u], __builtin_bit_cast(bf16x8, xr[2 * i + u]), a, 0, 0, 0);
+                    if (!(DBG & 2)) a = H16_MFMA_32x32x16(wf[i & 1][u], __builtin_bit_cast(h16x8, xr[2 * i + u]), a, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -517,9 +517,9 @@ __global__ __launch_bounds__(256, 3) void rowlin_kernel(const RLParams p, const 
                     for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            bf16x4 pk;
+                            h16x4 pk;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) pk[e] = (bf16)(bb ? a1[4 * q + e] : a0[4 * q + e]);
+                            for (int e = 0; e < 4; ++e) pk[e] = (h16)(bb ? a1[4 * q + e] : a0[4 * q + e]);
                             *reinterpret_cast<u32x2*>(slab + (l31 & 15) * 144 + (bb * 32 + 8 * q + 4 * half) * 2) = __builtin_bit_cast(u32x2, pk);
                         }
                 }
@@ -555,16 +555,20 @@ size_t ff_stream_bytes(int C) { return C == RC ? (size_t)RITER * RCHB : 0; }
 int pack_ff_stream(const void* w1_packed, const void* w2_packed, void* stream, int C, hipStream_t s) {
     if (C != RC) return DSIM_ERR_INVALID;
     const int n = RITER * (RCHB / 16);
-    hipLaunchKernelGGL(pack_ff_stream_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16*)w1_packed,
-                       (const bf16*)w2_packed, (char*)stream);
+    hipLaunchKernelGGL(pack_ff_stream_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const h16*)w1_packed,
+                       (const h16*)w2_packed, (char*)stream);
     DSIM_HIP_CHECK(hipGetLastError());
     return DSIM_OK;
 }
 
 int launch_ff_fused(const FFArgs& a, hipStream_t s) {
+#ifdef DSIM_HAS_F16_TWINS
+    if (a.dtype == DSIM_F16) return launch_ff_fused_f16(a, s);
+#endif
+    if (a.dtype != DSIM_H16) return DSIM_ERR_INVALID;
     if (a.C != RC || a.M < 1 || (size_t)a.M * RC * 2 >= 0x7fffffffull) return DSIM_ERR_INVALID;
     FFParams p;
-    p.x = (const bf16*)a.x; p.out = (bf16*)a.out; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.stream = (const char*)a.stream;
+    p.x = (const h16*)a.x; p.out = (h16*)a.out; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.stream = (const char*)a.stream;
     p.b1 = a.b1; p.b2 = a.b2; p.M = a.M; p.eps = a.eps;
     p.x_bytes = (unsigned)((size_t)a.M * RC * 2);
     p.stream_bytes = (unsigned)((size_t)RITER * RCHB);
@@ -598,15 +602,19 @@ size_t rowlin_stream_bytes(int C, int N) { return (C == RC && N % 64 == 0 && N <
 int pack_rowlin_stream(const void* w_packed, void* stream, int C, int N, hipStream_t s) {
     if (!rowlin_stream_bytes(C, N)) return DSIM_ERR_INVALID;
     const int n = N / 32 * (LCHB / 16);
-    hipLaunchKernelGGL(pack_rowlin_stream_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const bf16*)w_packed, (char*)stream, N);
+    hipLaunchKernelGGL(pack_rowlin_stream_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const h16*)w_packed, (char*)stream, N);
     DSIM_HIP_CHECK(hipGetLastError());
     return DSIM_OK;
 }
 
 int launch_rowlin(const RowLinArgs& a, hipStream_t s) {
+#ifdef DSIM_HAS_F16_TWINS
+    if (a.dtype == DSIM_F16) return launch_rowlin_f16(a, s);
+#endif
+    if (a.dtype != DSIM_H16) return DSIM_ERR_INVALID;
     if (!rowlin_stream_bytes(a.C, a.N) || a.M < 1 || (size_t)a.M * a.N * 2 >= 0x7fffffffull || !a.ln_g != !a.ln_b) return DSIM_ERR_INVALID;
     RLParams p;
-    p.x = (const bf16*)a.x; p.out = (bf16*)a.out; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.stream = (const char*)a.stream;
+    p.x = (const h16*)a.x; p.out = (h16*)a.out; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.stream = (const char*)a.stream;
     p.M = a.M; p.N = a.N; p.eps = a.eps;
     p.x_bytes = (unsigned)((size_t)a.M * RC * 2); p.out_bytes = (unsigned)((size_t)a.M * a.N * 2);
     p.stream_bytes = (unsigned)rowlin_stream_bytes(a.C, a.N);

@@ -73,7 +73,7 @@ struct Walk {
         if (!run || !h->profiling) return;
         (void)hipEventRecord(h->prof.back().e1, s);
     }
-    const char* dtn() const { return h->dt == DSIM_F32 ? "f32" : "bf16"; }
+    const char* dtn() const { return h->dt == DSIM_F32 ? "f32" : (h->dt == DSIM_F16 ? "f16" : "bf16"); }
 
     int gemm(GemmArgs& g) {
         g.zero_page = h->zero_page;
@@ -143,7 +143,7 @@ struct Walk {
     int attn(const AttnArgs& a) {
         if (!run) return DSIM_OK;
         // (key sequences >= 2048 run the fixed-reference instantiation attn_kernel<T, D, true>: its own family)
-        pbegin(std::string("attention_") + dtn() + "_d" + std::to_string(a.D) + (a.Nk >= 2048 && h->dt == DSIM_BF16 ? "_long" : "") +
+        pbegin(std::string("attention_") + dtn() + "_d" + std::to_string(a.D) + (a.Nk >= 2048 && h->dt != DSIM_F32 ? "_long" : "") +
                    "|B" + std::to_string(a.B) + " H" + std::to_string(a.H) +
                    " Nq" + std::to_string(a.Nq) + " Nk" + std::to_string(a.Nk),
                4.0 * a.B * a.H * (double)a.Nq * a.Nk * a.D,
@@ -228,7 +228,7 @@ struct Walk {
         const bool pre = half_in && blk == 0;            // still on the de-duplicated half batch
         const int Mx = pre ? Mh : M;
         void* hbx = pre ? hbh : hb;
-        // LayerNorm + projection as one row-resident launch where the width has one (bf16, C = 320; not the tapped block, whose
+        // LayerNorm + projection as one row-resident launch where the width has one (16-bit modes, C = 320; not the tapped block, whose
         // q, k, v go to three tensors)
         auto ln_proj = [&](const void* xin, const Packed* g, const Packed* be, const std::string& key, void* o, int Mr, int N) -> int {
             const auto it = h->pk.find(key);
@@ -236,7 +236,7 @@ struct Walk {
             if (run) {
                 RowLinArgs ra;
                 ra.x = xin; ra.out = o; ra.ln_g = (const float*)g->p; ra.ln_b = (const float*)be->p; ra.stream = it->second.p;
-                ra.M = Mr; ra.C = C; ra.N = N; ra.eps = 1e-5f;
+                ra.M = Mr; ra.C = C; ra.N = N; ra.eps = 1e-5f; ra.dtype = h->dt;
                 pbegin(std::string("ln_linear_") + dtn() + "|M" + std::to_string(Mr) + " N" + std::to_string(N) + " K" + std::to_string(C),
                        2.0 * Mr * (double)C * N, (double)Mr * (C + N) * es() + (double)C * N * es());
                 const int st = launch_rowlin(ra, s);
@@ -318,14 +318,14 @@ struct Walk {
         }
         CK(linear(big, C, nullptr, 0, o2w, o2b, hb, hb, M, C, C));
         // feed-forward: norm3 -> Linear(C,8C) -> h*gelu(g) -> Linear(4C,C) -> + residual.  One row-resident launch where
-        // the width has one (bf16, C = 320); else LayerNorm, the GEGLU GEMM (h*gelu(g) in its epilogue) and ff.net.2.
+        // the width has one (16-bit modes, C = 320); else LayerNorm, the GEGLU GEMM (h*gelu(g) in its epilogue) and ff.net.2.
         const auto fst = h->pk.find(b + "ff.stream");
         if (fst != h->pk.end() && (h->fusion & DSIM_FUSE_FF)) {
             if (run) {
                 FFArgs fa;
                 fa.x = hb; fa.out = hb; fa.ln_g = (const float*)l3w->p; fa.ln_b = (const float*)l3b->p;
                 fa.stream = fst->second.p; fa.b1 = (const float*)f1b->p; fa.b2 = (const float*)f2b->p; fa.M = M; fa.C = C;
-                fa.eps = 1e-5f;
+                fa.eps = 1e-5f; fa.dtype = h->dt;
                 pbegin(std::string("ff_fused_") + dtn() + "|M" + std::to_string(M) + " C" + std::to_string(C),
                        2.0 * M * (double)C * 12 * C, 2.0 * M * (double)C * es() + 12.0 * C * C * es());
                 const int st = launch_ff_fused(fa, s);
@@ -518,7 +518,7 @@ int dsim_device_count(void) {
 int dsim_unet_create(const dsim_unet_cfg* cfg, dsim_unet** out) {
     if (!cfg || !out) return DSIM_ERR_INVALID;
     if (cfg->n_levels < 1 || cfg->n_levels > DSIM_MAX_LEVELS) return DSIM_ERR_INVALID;
-    if (cfg->compute_dtype != DSIM_F32 && cfg->compute_dtype != DSIM_BF16) return DSIM_ERR_INVALID;
+    if (cfg->compute_dtype != DSIM_F32 && cfg->compute_dtype != DSIM_BF16 && cfg->compute_dtype != DSIM_F16) return DSIM_ERR_INVALID;
     int t, hh, d;
     CK(tap_geometry(*cfg, &t, &hh, &d));
     if (dsim_device_count() < 1) return DSIM_ERR_NO_DEVICE;
@@ -572,8 +572,8 @@ int dsim_unet_finalize(dsim_unet* h, void* stream) {
             h->pk[p + suffix] = P;
         }
     }
-    // fused feed-forward (rowres.hip): one weight stream per transformer block of a width the kernel covers (bf16 only)
-    if (h->dt == DSIM_BF16) {
+    // fused feed-forward (rowres.hip): one weight stream per transformer block of a width the kernel covers (16-bit modes only)
+    if (h->dt != DSIM_F32) {
         std::vector<std::string> ffs;
         for (auto& kv : h->pk)
             if (ends_with(kv.first, "ff.net.0.proj.weight") && ff_stream_bytes(kv.second.cols)) ffs.push_back(kv.first);

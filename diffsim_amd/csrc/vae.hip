@@ -194,8 +194,11 @@ struct VWalk {
         if (run) {
             const size_t total = (size_t)M * Cm;
             if (h->dt == DSIM_BF16)
-                hipLaunchKernelGGL(to_nchw_f32_kernel<bf16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                                   (const bf16*)mo, moments, x.H * x.W, Cm, total);
+                hipLaunchKernelGGL(to_nchw_f32_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                                   (const bf16_t*)mo, moments, x.H * x.W, Cm, total);
+            else if (h->dt == DSIM_F16)
+                hipLaunchKernelGGL(to_nchw_f32_kernel<f16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                                   (const f16_t*)mo, moments, x.H * x.W, Cm, total);
             else
                 hipLaunchKernelGGL(to_nchw_f32_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                                    (const float*)mo, moments, x.H * x.W, Cm, total);
@@ -212,7 +215,7 @@ extern "C" {
 int dsim_vae_create(const dsim_vae_cfg* cfg, dsim_vae** out) {
     if (!cfg || !out) return DSIM_ERR_INVALID;
     if (cfg->n_levels < 1 || cfg->n_levels > DSIM_MAX_LEVELS) return DSIM_ERR_INVALID;
-    if (cfg->compute_dtype != DSIM_F32 && cfg->compute_dtype != DSIM_BF16) return DSIM_ERR_INVALID;
+    if (cfg->compute_dtype != DSIM_F32 && cfg->compute_dtype != DSIM_BF16 && cfg->compute_dtype != DSIM_F16) return DSIM_ERR_INVALID;
     if (dsim_device_count() < 1) return DSIM_ERR_NO_DEVICE;
     dsim_vae* h = new dsim_vae();
     h->cfg = *cfg;
@@ -260,8 +263,11 @@ int dsim_vae_finalize(dsim_vae* h, void* stream) {
     CK(h->dalloc((size_t)Cm * 4, &fb.p));
     fb.rows = Cm; fb.cols = 1;
     if (h->dt == DSIM_BF16)
-        hipLaunchKernelGGL(fold_quant_kernel<bf16>, dim3((K + 255) / 256, Cm), dim3(256), 0, s, wq32, (const bf16*)cow->p,
-                           (bf16*)fw.p, Cm, K);
+        hipLaunchKernelGGL(fold_quant_kernel<bf16_t>, dim3((K + 255) / 256, Cm), dim3(256), 0, s, wq32, (const bf16_t*)cow->p,
+                           (bf16_t*)fw.p, Cm, K);
+    else if (h->dt == DSIM_F16)
+        hipLaunchKernelGGL(fold_quant_kernel<f16_t>, dim3((K + 255) / 256, Cm), dim3(256), 0, s, wq32, (const f16_t*)cow->p,
+                           (f16_t*)fw.p, Cm, K);
     else
         hipLaunchKernelGGL(fold_quant_kernel<float>, dim3((K + 255) / 256, Cm), dim3(256), 0, s, wq32, (const float*)cow->p,
                            (float*)fw.p, Cm, K);

@@ -61,8 +61,10 @@ class DiffSim:
             raise NotImplementedError("IP-Adapter mode is out of scope (SURVEY.md section 2 row 3)")
         if state_dict is None:
             raise ValueError("state_dict (diffusers-keyed U-Net weights) is required: no checkpoint is bundled")
-        if torch_dtype == torch.float16:
-            torch_dtype = torch.bfloat16        # the MFMA path computes in bf16; fp32 is the parity mode
+        # torch.float16 is what every reference driver passes (cute_main.py:31): the kernels then compute in IEEE fp16
+        # (v_mfma_f32_16x16x32_f16, same rate as bf16); torch.bfloat16 is the headline mode, torch.float32 the parity mode
+        if torch_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError("torch_dtype must be torch.float32, torch.bfloat16 or torch.float16")
         self.dtype = torch_dtype
         self.device = torch.device("cuda:0" if device == "cuda" else device)
         self.ip_adapter = False

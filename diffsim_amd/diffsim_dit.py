@@ -26,7 +26,7 @@ class diffsim_DiT:
         if img_size // 8 != dit_config.input_size:
             raise ValueError("img_size must be 8 * dit_config.input_size")
         self.cfg, self.state_dict, self.vae = dit_config, state_dict, vae
-        self.dtype = torch.bfloat16 if torch_dtype == torch.float16 else torch_dtype
+        self.dtype = torch_dtype
         self.device = torch.device("cuda:0" if device == "cuda" else device)
         self.fp8_attention = fp8_attention      # e4m3 MFMAs for QK^T and PV inside the DiT blocks (opt-in)
         self._engine: Optional[DiTEngine] = None

@@ -29,8 +29,6 @@ class diffsim_xl:
             raise NotImplementedError("IP-Adapter mode is out of scope")
         if state_dict is None:
             raise ValueError("state_dict (diffusers-keyed SDXL U-Net weights) is required")
-        if torch_dtype == torch.float16:
-            torch_dtype = torch.bfloat16
         self.dtype = torch_dtype
         self.device = torch.device("cuda:0" if device == "cuda" else device)
         self.ip_adapter = False

@@ -87,8 +87,8 @@ class UNetEngine:
 
     def __init__(self, cfg: UNetConfig, state_dict: Dict[str, torch.Tensor], dtype: torch.dtype = torch.bfloat16,
                  target_block: str = "up_blocks", target_layer: int = 0, device: str = "cuda:0"):
-        if dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("compute dtype must be float32 (parity mode) or bfloat16")
+        if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError("compute dtype must be float32 (parity mode), bfloat16 or float16")
         self.L = _lib.lib()
         if not torch.cuda.is_available():
             raise _lib.DsimError("no GPU visible: the DiffSim engine runs only on the HIP device")
@@ -325,8 +325,8 @@ def pair_score(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, idx_a: torch.T
     _require_cuda(q, k, v, idx_a, idx_b)
     if similarity not in ("cosine", "mse"):
         raise ValueError(similarity)
-    if q.dtype not in (torch.float32, torch.bfloat16) or k.dtype != q.dtype or v.dtype != q.dtype:
-        raise _lib.DsimError("q,k,v must share dtype float32 or bfloat16")
+    if q.dtype not in (torch.float32, torch.bfloat16, torch.float16) or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise _lib.DsimError("q,k,v must share dtype float32, bfloat16 or float16")
     if idx_a.dtype != torch.int32 or idx_b.dtype != torch.int32:
         raise _lib.DsimError("pair indices must be int32")
     nf, B, N, HD = q.shape

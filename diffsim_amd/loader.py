@@ -38,7 +38,15 @@ def _find_weights(folder: str):
         p = os.path.join(folder, name)
         if os.path.exists(p):
             return [p]
-    idx = sorted(glob.glob(os.path.join(folder, "*.safetensors.index.json")))
+    # sharded checkpoints: probe the index names in the single-file order (fp32 first, then the fp16 variant) -- a plain sorted
+    # glob would pick "...fp16.safetensors.index.json" before "...safetensors.index.json"; an index of another name is taken
+    # only when it is the only one
+    idx = [p for p in (os.path.join(folder, n + ".index.json") for n in _WEIGHT_NAMES) if os.path.exists(p)]
+    if not idx:
+        idx = sorted(glob.glob(os.path.join(folder, "*.safetensors.index.json")))
+        if len(idx) > 1:
+            raise FileNotFoundError(f"{folder} holds several *.safetensors.index.json files of unknown names: "
+                                    f"{[os.path.basename(c) for c in idx]}")
     if idx:
         with open(idx[0]) as f:
             shards = sorted(set(json.load(f)["weight_map"].values()))
@@ -149,13 +157,13 @@ class LazyTokenizer:
 
 
 def _torch_dtype(name: str) -> torch.dtype:
-    """Compute dtype of the kernels: bf16 (the MFMA path) or fp32 (parity mode).  There is no fp16 kernel mode; the
-    reference's fp16 *pipeline arithmetic* is --noise_dtype fp16."""
+    """Compute dtype of the kernels: bf16 (the headline MFMA mode), fp16 (the type the reference's drivers construct their
+    pipelines in; same MFMA rate) or fp32 (parity mode).  The reference's fp16 *pipeline arithmetic* outside the U-Net
+    (generator draws, add_noise) is --noise_dtype fp16."""
     try:
-        return {"bf16": torch.bfloat16, "fp32": torch.float32}[name]
+        return {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16}[name]
     except KeyError:
-        raise ValueError(f"--dtype {name!r}: the engine computes in bf16 or fp32 (for the reference's fp16 pipeline "
-                         f"arithmetic use --noise_dtype fp16)") from None
+        raise ValueError(f"--dtype {name!r}: the engine computes in bf16, fp16 or fp32") from None
 
 
 def load_diffsim(model_path: str, dtype: str = "bf16", device: str = "cuda", noise_dtype=torch.float32, **kw):

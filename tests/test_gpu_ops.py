@@ -1,6 +1,6 @@
 """Kernel-level parity: every HIP operator, called through the C ABI, against the same op in
 plain torch fp32 on the CPU.  fp32 mode must agree to ~1e-5 (exact-f32 MFMA, different summation
-order); bf16 mode is compared on bf16-rounded inputs with a bf16-sized tolerance."""
+order); the 16-bit modes (bf16, fp16) are compared on inputs rounded to the compute dtype with a tolerance sized to it."""
 import math
 
 import numpy as np
@@ -10,11 +10,12 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
 
 
 def _tol(dtype):
-    return (2e-5, 2e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+    # bf16: 8 significant bits; fp16 (the reference drivers' dtype): 11
+    return (2e-5, 2e-5) if dtype == torch.float32 else ((2e-2, 2e-2) if dtype == torch.bfloat16 else (3e-3, 3e-3))
 
 
 def _dev(t, dtype=None):
@@ -446,14 +447,15 @@ def test_ln_linear_320(eng, M, N, ln):
             eng.op_ln_linear(torch.zeros(8, bad[0], dtype=dtype, device="cuda"), None, None, torch.zeros(bad[1], bad[0], device="cuda"))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("Nq,Nk", [(300, 2048), (256, 4096), (300, 4096)])
-def test_attention_pipelined_kernel_takes_the_exact_fallback(eng, Nq, Nk):
+def test_attention_pipelined_kernel_takes_the_exact_fallback(eng, Nq, Nk, dtype):
     """attn_long_kernel itself (bf16, d = 40, Nk >= 2048 and Nk % 64 == 0: SD1.5's 4096-key self-attention, the headline path)
     through its exact-softmax fallback: the forced cases of test_attention_long_keys_fixed_reference_softmax use Nk = 2048 + 77,
     which routes to attn_kernel / attend_checked.  Here the spike sits at a key far down a sequence the pipelined kernel owns, so
     its __syncthreads_or(bad) and the two exact re-runs over the 3-deep ring execute; ragged Nq exercises the partial last
-    query block through the same path.  The spiked workgroup and an un-spiked one (other head, other query block) are checked."""
-    dtype = torch.bfloat16
+    query block through the same path.  The spiked workgroup and an un-spiked one (other head, other query block) are checked.
+    In fp16 the "late spike" (P = 2^40 relative to tile 0) already exceeds the type's range, so it takes the fallback too."""
     B, H, D = 1, 2, 40
     g = torch.Generator().manual_seed(Nq + Nk)
     q = torch.randn(B, Nq, H * D, generator=g)
@@ -486,14 +488,14 @@ def test_attention_pipelined_kernel_takes_the_exact_fallback(eng, Nq, Nk):
                 assert (got[0, r, :D].float().cpu() - vh[0, key, :D]).abs().max().item() < 2e-2, (case, r)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("D", [40, 64, 80])
-def test_attention_long_keys_fixed_reference_softmax(eng, D):
+def test_attention_long_keys_fixed_reference_softmax(eng, D, dtype):
     """Key sequences >= 2048 take the fixed-reference softmax (the maximum is fixed after key tile 0, later tiles never look
     at their scores; attention.hip attend<FAST>).  (1) ordinary data; (2) the rare branch, FORCED (cdna_hip_programming.md rule
     26): one key far down the sequence scores ~+40 (log2 units) above everything in tile 0 for some rows -> P up to 2^40,
     still exact after normalisation; (3) a key ~+300 above -> exp2 overflows in the fast form, the end-of-block check must
     send the workgroup through the exact running-maximum form.  All against float64 SDPA over the whole tensor."""
-    dtype = torch.bfloat16
     B, H, Nq, Nk = 1, 2, 256, 2048 + 77
     g = torch.Generator().manual_seed(D)
     q = torch.randn(B, Nq, H * D, generator=g)

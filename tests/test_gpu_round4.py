@@ -1,0 +1,119 @@
+"""Round-4 features through the C ABI: the fp16 compute mode (the arithmetic type every reference driver constructs its
+pipeline in, /root/reference/cute_main.py:31, /root/reference/diffsim/diffsim.py:82) against the CPU oracle and the fp32
+kernel mode, its overflow guard, and bit-identity properties it must share with the bf16 mode."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from diffsim_amd import config as C
+from diffsim_amd import synth as S
+
+
+def _scorer(cfg, sd, dtype, **kw):
+    from diffsim_amd.diffsim import DiffSim
+    return DiffSim(torch_dtype=dtype, device="cuda", unet_config=cfg, state_dict=sd, **kw)
+
+
+@pytest.fixture(scope="module")
+def tiny_env():
+    from oracle import cpu_ref as R
+    sd = S.make_state_dict(C.TINY, seed=0)
+    return dict(sd=sd, oracle=R.build_unet(R.TINY, sd), ctx=S.make_context(C.TINY), R=R)
+
+
+@pytest.mark.parametrize("block,layer,step", [("up_blocks", 0, 600), ("up_blocks", 2, 900), ("down_blocks", 1, 600), ("mid_blocks", 0, 900)])
+def test_tiny_fp16_features_and_scores(tiny_env, block, layer, step):
+    """torch.float16 is honoured (no silent bf16 substitution): q/k/v come back as fp16 tensors, within an fp16-sized bound of
+    the oracle's, tighter than the bf16 mode's; cosine and mse scores within 2e-3 of the oracle."""
+    R, unet, ctx = tiny_env["R"], tiny_env["oracle"], tiny_env["ctx"]
+    ds = _scorer(C.TINY, tiny_env["sd"], torch.float16)
+    assert ds.dtype == torch.float16
+    zA, zB = S.make_pair_latents(C.TINY, 3)
+    n = S.draw_pair_noise(2334, zA.shape)
+    q, k, v = ds.features(torch.cat([zA, zB]), torch.cat([n[2], n[3]]), ctx, block, layer, step)
+    assert q.dtype == torch.float16 and k.dtype == torch.float16 and v.dtype == torch.float16
+    db = _scorer(C.TINY, tiny_env["sd"], torch.bfloat16)
+    qb, kb, vb = db.features(torch.cat([zA, zB]), torch.cat([n[2], n[3]]), ctx, block, layer, step)
+    e16 = eb = 0.0
+    for img, (z, nz) in enumerate(((zA, n[2]), (zB, n[3]))):
+        qo, ko, vo = R.features(unet, z, nz, ctx, step, block, layer)
+        for got, gotb, want in ((q, qb, qo), (k, kb, ko), (v, vb, vo)):
+            want = want.transpose(1, 2).reshape(2, want.shape[2], -1)
+            sc = max(float(want.abs().max()), 1.0)
+            e16 = max(e16, (got[img].float().cpu() - want).abs().max().item() / sc)
+            eb = max(eb, (gotb[img].float().cpu() - want).abs().max().item() / sc)
+    assert e16 <= 6e-3, e16
+    assert e16 < eb, (e16, eb)               # three more significant bits than bf16
+    for sim in ("cosine", "mse"):
+        s = float(ds.diffsim_latents(zA, zB, n[2], n[3], ctx, block, layer, step, sim).cpu())
+        so = float(R.diffsim_latents(unet, zA, zB, n[2], n[3], ctx, step, block, layer, sim))
+        assert abs(s - so) <= 2e-3 * max(abs(so), 1.0), (sim, s, so)
+
+
+def test_fp16_batch_invariance_and_fused_kernels(tiny_env):
+    """batch-of-N == N singles bit for bit, repeat calls bit-identical, and the multi-operator launches (fusion mask) against
+    their unfused chains, in fp16 as in bf16."""
+    ds = _scorer(C.TINY, tiny_env["sd"], torch.float16)
+    ctx = tiny_env["ctx"]
+    lats = [S.make_pair_latents(C.TINY, i) for i in range(5)]
+    n = S.draw_pair_noise(2334, lats[0][0].shape)
+    zA = torch.cat([p[0] for p in lats]); zB = torch.cat([p[1] for p in lats])
+    s_all = ds.score_latent_pairs(zA, zB, n[2], n[3], ctx)
+    assert torch.equal(s_all, ds.score_latent_pairs(zA, zB, n[2], n[3], ctx))
+    for i in range(5):
+        assert torch.equal(ds.score_latent_pairs(zA[i:i + 1], zB[i:i + 1], n[2], n[3], ctx)[0], s_all[i])
+    unf = _scorer(C.TINY, tiny_env["sd"], torch.float16, fusion=0)
+    s_unf = unf.score_latent_pairs(zA, zB, n[2], n[3], ctx)
+    assert (s_all - s_unf).abs().max().item() <= 2e-3
+
+
+def test_sd15_full_size_fp16_pairs():
+    """The real SD1.5 graph at 512 px in fp16 against the fp32 kernel mode (itself within 1e-4 of the CPU oracle:
+    test_gpu_e2e.py::test_sd15_full_size_fp32_and_bf16_pairs): score error <= 5e-4 and below the bf16 mode's; every kernel
+    family of the step runs its fp16 twin (ff_fused, ln_linear, the pipelined 4096-key attention), no pair flagged."""
+    cfg = C.SD15
+    keys = [k for k in C.unet_param_shapes(cfg) if not k.startswith(("up_blocks.2", "up_blocks.3", "conv_norm_out", "conv_out"))]
+    sd = S.make_state_dict(cfg, seed=0, keys=keys)
+    ctx = S.make_context(cfg)
+    n = S.draw_pair_noise(2334, (1, 4, 64, 64))
+    lats = [S.make_pair_latents(cfg, i) for i in range(4)]
+    zA = torch.cat([p[0] for p in lats]); zB = torch.cat([p[1] for p in lats])
+    want = _scorer(cfg, sd, torch.float32).score_latent_pairs(zA, zB, n[2], n[3], ctx).cpu()
+    s16 = _scorer(cfg, sd, torch.float16)
+    got16 = s16.score_latent_pairs(zA, zB, n[2], n[3], ctx)
+    gotb = _scorer(cfg, sd, torch.bfloat16).score_latent_pairs(zA, zB, n[2], n[3], ctx).cpu()
+    e16 = (got16.cpu() - want).abs().max().item()
+    eb = (gotb - want).abs().max().item()
+    assert torch.isfinite(got16).all()
+    assert e16 <= 5e-4, (e16, eb)
+    assert e16 < eb, (e16, eb)
+    eng = s16.engine("up_blocks", 0)
+    eng.profile(True)
+    s16.score_latent_pairs(zA, zB, n[2], n[3], ctx)
+    fams = {r[0] for r in eng.profile_records()}
+    eng.profile(False)
+    for f in ("ff_fused_f16", "ln_linear_f16", "attention_f16_d40_long", "gemm_f16_256x320_conv3"):
+        assert f in fams, (f, sorted(fams))
+
+
+def test_fp16_overflow_is_reported_per_pair():
+    """fp16 tops out at 65504: a pair whose features overflow is flagged by the per-pair status (dsim_pair_score_status) and its
+    score is not a silent finite number; its neighbours in the batch are untouched."""
+    from diffsim_amd.engine import pair_score
+    g = torch.Generator("cpu").manual_seed(0)
+    q, k, v = (torch.randn((4, 2, 64, 4 * 32), generator=g).cuda().to(torch.float16) for _ in range(3))
+    v[2, 1, 5, 7] = float("inf")                      # what an overflowed activation looks like in fp16
+    ia = torch.tensor([0, 0, 2, 1], dtype=torch.int32, device="cuda")
+    ib = torch.tensor([1, 2, 3, 3], dtype=torch.int32, device="cuda")
+    s, st = pair_score(q, k, v, ia, ib, 4, "cosine", return_status=True)
+    assert st.tolist() == [0, 1, 1, 0], st.tolist()
+    assert torch.isfinite(s[[0, 3]]).all() and not torch.isfinite(s[[1, 2]]).any()
+    # ... and against float64 SDPA on the clean pairs
+    qf, kf, vf = (t.double().cpu().view(4, 2, 64, 4, 32).permute(0, 1, 3, 2, 4) for t in (q, k, v))
+    import torch.nn.functional as F
+    for p, (a, b) in ((0, (0, 1)), (3, (1, 3))):
+        oab = F.scaled_dot_product_attention(qf[a], kf[b], vf[b]); oaa = F.scaled_dot_product_attention(qf[a], kf[a], vf[a])
+        oba = F.scaled_dot_product_attention(qf[b], kf[a], vf[a]); obb = F.scaled_dot_product_attention(qf[b], kf[b], vf[b])
+        w = 0.5 * (F.cosine_similarity(oab.flatten(), oaa.flatten(), dim=0) + F.cosine_similarity(oba.flatten(), obb.flatten(), dim=0))
+        assert abs(float(s[p]) - float(w)) <= 2e-3, (p, float(s[p]), float(w))

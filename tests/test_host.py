@@ -201,7 +201,8 @@ def test_public_header_is_plain_c99(tmp_path):
 
 def test_loader_reads_sharded_checkpoints_and_refuses_ambiguity(tmp_path):
     """loader.load_state_dict: a *.safetensors.index.json checkpoint is merged from all its shards; several unindexed
-    files, a missing shard, repeated keys and the removed 'fp16' compute-dtype alias raise instead of loading a part."""
+    files, a missing shard, repeated keys and an unknown compute dtype raise instead of loading a part; of two indexes the
+    fp32 one is read."""
     import json as _json
     import torch
     from safetensors.torch import save_file
@@ -220,8 +221,17 @@ def test_loader_reads_sharded_checkpoints_and_refuses_ambiguity(tmp_path):
     (d / "diffusion_pytorch_model-00002-of-00002.safetensors").unlink()
     with pytest.raises(FileNotFoundError, match="not there"):
         loader.load_state_dict(str(d))
-    with pytest.raises(ValueError, match="bf16 or fp32"):
-        loader._torch_dtype("fp16")
+    with pytest.raises(ValueError, match="bf16, fp16 or fp32"):
+        loader._torch_dtype("fp8")
+    assert loader._torch_dtype("fp16") == torch.float16
+    # both indexes present: the fp32 one wins, as for single files (a sorted glob would take the fp16 variant)
+    d2 = tmp_path / "unet2"
+    d2.mkdir()
+    save_file({"a.weight": torch.ones(2)}, str(d2 / "full.safetensors"))
+    save_file({"a.weight": torch.zeros(2)}, str(d2 / "half.safetensors"))
+    (d2 / "diffusion_pytorch_model.safetensors.index.json").write_text(_json.dumps({"weight_map": {"a.weight": "full.safetensors"}}))
+    (d2 / "diffusion_pytorch_model.fp16.safetensors.index.json").write_text(_json.dumps({"weight_map": {"a.weight": "half.safetensors"}}))
+    assert float(loader.load_state_dict(str(d2))["a.weight"][0]) == 1.0
     assert loader._json(str(tmp_path / "nowhere")) == {}
 
 

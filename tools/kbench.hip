@@ -1,6 +1,6 @@
 // Kernel micro-benchmark (development aid, not part of the product): times the GEMM / conv /
 // attention / norm kernels on the exact shapes of one SD1.5 step (B2 U-Net batch elements) with HIP
-// events, random bf16 data.  Build: python tools/build_kbench.py ; run on the GPU box:
+// events, random h16 data.  Build: python tools/build_kbench.py ; run on the GPU box:
 //   ./tools/kbench [B2=64] [iters=10] [filter]
 #include <algorithm>
 #include <cstdio>
@@ -15,12 +15,12 @@ using namespace dsim;
 
 #define HC(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
-__global__ void fill_bf16(bf16* p, size_t n, unsigned seed, float scale) {
+__global__ void fill_bf16(h16* p, size_t n, unsigned seed, float scale) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     unsigned x = (unsigned)(i * 2654435761u) ^ seed;
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-    p[i] = (bf16)(((float)(x & 0xffff) / 32768.0f - 1.0f) * scale);
+    p[i] = (h16)(((float)(x & 0xffff) / 32768.0f - 1.0f) * scale);
 }
 __global__ void fill_f32(float* p, size_t n, unsigned seed, float scale) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -45,7 +45,7 @@ __global__ void bitdiff_kernel(const unsigned short* a, const unsigned short* b,
 static void* dalloc_bf16(size_t n, unsigned seed, float scale = 1.0f) {
     void* p;
     HC(hipMalloc(&p, n * 2 + 256));
-    hipLaunchKernelGGL(fill_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (bf16*)p, n, seed, scale);
+    hipLaunchKernelGGL(fill_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (h16*)p, n, seed, scale);
     return p;
 }
 static float* dalloc_f32(size_t n, unsigned seed, float scale = 1.0f) {

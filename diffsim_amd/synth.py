@@ -57,6 +57,48 @@ def make_state_dict(cfg: UNetConfig, seed: int = 0, keys: Optional[Sequence[str]
     return out
 
 
+def add_checkpoint_like_outliers(sd: Dict[str, torch.Tensor], seed: int = 5, conv_gain: float = 40.0, qk_gain: float = 5.0
+                                 ) -> Dict[str, torch.Tensor]:
+    """What trained checkpoints have and `make_state_dict` does not: (1) a few OUTLIER CHANNELS -- three output channels of
+    every ResnetBlock2D conv scaled by `conv_gain` (weights and bias), so GroupNorm groups are dominated by one channel and
+    the bf16 / fp16 range is exercised; (2) PEAKED attention -- the rows of one head of every self-attention to_q / to_k
+    scaled by `qk_gain` (logits of that head x gain^2: near one-hot softmax rows, and at the 4096-key level scores far
+    above key tile 0's maximum, i.e. the fixed-reference softmax's exact fallback, inside the U-Net).  Returns a modified copy."""
+    out = dict(sd)
+    g = torch.Generator("cpu").manual_seed(seed)
+    for k in sorted(sd):
+        t = sd[k]
+        if (".resnets." in k and (k.endswith("conv1.weight") or k.endswith("conv2.weight"))) and t.ndim == 4:
+            ch = torch.randperm(t.shape[0], generator=g)[:3]
+            t = t.clone()
+            t[ch] *= conv_gain
+            out[k] = t
+            b = k[:-len("weight")] + "bias"
+            if b in sd:
+                tb = sd[b].clone()
+                tb[ch] *= conv_gain
+                out[b] = tb
+        elif ".attn1." in k and (k.endswith("to_q.weight") or k.endswith("to_k.weight")):
+            t = t.clone()
+            hd = 40 if t.shape[0] % 40 == 0 else 8            # one head's rows (SD1.5 heads are 40 / 80 / 160 wide)
+            t[:hd] *= qk_gain
+            out[k] = t
+    return out
+
+
+def make_heavy_tailed_latents(cfg: UNetConfig, pair_index: int, base_seed: int = 4321) -> Tuple[torch.Tensor, torch.Tensor]:
+    """A latent pair with Student-t-like tails (a normal scaled by 1/sqrt(chi^2_3 / 3) per element, clipped at +-12):
+    real VAE latents of saturated images are not Gaussian."""
+    g = torch.Generator("cpu").manual_seed(base_seed + pair_index)
+    s = cfg.sample_size
+    zs = []
+    for _ in range(2):
+        z = torch.randn((1, cfg.in_channels, s, s), generator=g)
+        chi = (torch.randn((3, 1, cfg.in_channels, s, s), generator=g) ** 2).sum(0) / 3.0
+        zs.append((z / chi.sqrt().clamp_min(0.05)).clamp(-12.0, 12.0))
+    return zs[0], zs[1]
+
+
 def make_context(cfg: UNetConfig, seed: int = 77) -> torch.Tensor:
     """Stand-in for [CLIP(""), CLIP(prompt)] (diffsim_pipeline.py:125-141): (2, L, Dc) fp32."""
     g = torch.Generator("cpu").manual_seed(seed)

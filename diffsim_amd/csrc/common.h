@@ -176,6 +176,10 @@ int prep_conv_in(const float* lat, const float* noise /*nullable*/, float sa, fl
 int convert_f32_to(const float* src, void* dst, int dtype, size_t n, hipStream_t s);
 // out[2b], out[2b+1] = in[b]: a batch element becomes its two classifier-free-guidance copies (bytes_per_elem % 16 == 0)
 int dup_batch(const void* in, void* out, int n_batch, size_t bytes_per_elem, hipStream_t s);
+// token-major nearest-neighbour resize [B][Hin][Win][C] -> [B][Hout][Wout][C] (row_bytes = C * element size, % 16 == 0), source
+// index = min(floor(dst * (float)in / out), in - 1) as F.interpolate(mode="nearest") computes it: the explicit-size
+// upsample of latent sides that are not a multiple of 2**levels (diffusers' forward_upsample_size)
+int resize_nearest(const void* in, void* out, int B, int Hin, int Win, int Hout, int Wout, size_t row_bytes, hipStream_t s);
 
 // row-resident Linear for K = 320 (optionally behind a LayerNorm): out[M][N] = LN?(x) W^T (+ bias), N % 64 == 0, N <= 960 -- rowres.hip
 struct RowLinArgs {

@@ -355,6 +355,31 @@ int dup_batch(const void* in, void* out, int n_batch, size_t bytes_per_elem, hip
     return DSIM_OK;
 }
 
+namespace {
+__global__ void resize_nearest_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, int Hin, int Win, int Hout, int Wout,
+                                      int cpr /*16-byte chunks per pixel*/, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % cpr);
+    const size_t pix = i / cpr;
+    const int ox = (int)(pix % Wout), oy = (int)((pix / Wout) % Hout);
+    const size_t b = pix / ((size_t)Wout * Hout);
+    // torch's nearest: scale = (float)in / out, src = min((int)floorf(dst * scale), in - 1)
+    const float sy = (float)Hin / (float)Hout, sx = (float)Win / (float)Wout;
+    const int iy = min((int)floorf((float)oy * sy), Hin - 1), ix = min((int)floorf((float)ox * sx), Win - 1);
+    out[i] = in[((b * Hin + iy) * Win + ix) * cpr + c];
+}
+}  // namespace
+int resize_nearest(const void* in, void* out, int B, int Hin, int Win, int Hout, int Wout, size_t row_bytes, hipStream_t s) {
+    if (row_bytes % 16 || B < 1 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1) return DSIM_ERR_INVALID;
+    const int cpr = (int)(row_bytes / 16);
+    const size_t total = (size_t)B * Hout * Wout * cpr;
+    hipLaunchKernelGGL(resize_nearest_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const u32x4*)in, (u32x4*)out, Hin, Win,
+                       Hout, Wout, cpr, total);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
+
 int convert_f32_to(const float* src, void* dst, int dtype, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, dtype, n);
     DSIM_HIP_CHECK(hipGetLastError());

@@ -109,11 +109,15 @@ struct Walk {
     int conv3(const Act& x, const Packed* w, const float* bias, const void* residual, void* out, int Cout, int stride,
               int ups, const float* bias_odd = nullptr) {
         GemmArgs g;
-        if (h->two_temb && bias_odd) { g.bias2 = bias_odd; g.rows_per_batch = (ups ? 4 : 1) * x.H * x.W / (stride == 2 ? 4 : 1); }
+        if (h->two_temb && bias_odd) {
+            g.bias2 = bias_odd;
+            g.rows_per_batch = ups ? 4 * x.H * x.W : (stride == 2 ? ((x.H + 1) / 2) * ((x.W + 1) / 2) : x.H * x.W);
+        }
         g.A0 = x.p; g.C0 = x.C; g.mode = GEMM_CONV3;
         g.Hin = x.H; g.Win = x.W;
-        g.Hout = ups ? x.H * 2 : (stride == 2 ? x.H / 2 : x.H);
-        g.Wout = ups ? x.W * 2 : (stride == 2 ? x.W / 2 : x.W);
+        // stride 2, padding 1, kernel 3: (H - 1) / 2 + 1 rows, i.e. ceil(H / 2) (odd sides: --image_size 224 -> 28 -> 14 -> 7 -> 4)
+        g.Hout = ups ? x.H * 2 : (stride == 2 ? (x.H + 1) / 2 : x.H);
+        g.Wout = ups ? x.W * 2 : (stride == 2 ? (x.W + 1) / 2 : x.W);
         g.stride = stride; g.ups = ups;
         g.M = B2 * g.Hout * g.Wout; g.N = Cout; g.K = 9 * x.C;
         g.W = w->p; g.bias = bias;
@@ -405,7 +409,7 @@ struct Walk {
             }
             if (i != nl - 1) {
                 WGET(dw, bp + "downsamplers.0.conv.weight"); WGET(db, bp + "downsamplers.0.conv.bias");
-                Act d{alloc_act((size_t)B2 * (x.H / 2) * (x.W / 2) * co), co, x.H / 2, x.W / 2};
+                Act d{alloc_act((size_t)B2 * ((x.H + 1) / 2) * ((x.W + 1) / 2) * co), co, (x.H + 1) / 2, (x.W + 1) / 2};
                 CK(conv3(x, dw, (const float*)db->p, nullptr, d.p, co, 2, 0));
                 x = d;
                 skips.push_back(x);
@@ -448,8 +452,22 @@ struct Walk {
             }
             if (i != nl - 1) {
                 WGET(uw, bp + "upsamplers.0.conv.weight"); WGET(ub, bp + "upsamplers.0.conv.bias");
-                Act u{alloc_act((size_t)B2 * (x.H * 2) * (x.W * 2) * co), co, x.H * 2, x.W * 2};
-                CK(conv3(x, uw, (const float*)ub->p, nullptr, u.p, co, 1, 1));
+                // the upsampled size is the next skip's (diffusers' upsample_size, hacked_modules.py:531-533): twice the side
+                // except below an odd level, where the nearest-neighbour resize to the explicit size runs as its own launch
+                const int th = skips.empty() ? x.H * 2 : skips.back().H, tw = skips.empty() ? x.W * 2 : skips.back().W;
+                Act u{alloc_act((size_t)B2 * th * tw * co), co, th, tw};
+                if (th == 2 * x.H && tw == 2 * x.W) {
+                    CK(conv3(x, uw, (const float*)ub->p, nullptr, u.p, co, 1, 1));      // x2 folded into the conv's gather
+                } else {
+                    Act rz{alloc_act((size_t)B2 * th * tw * co), co, th, tw};
+                    if (run) {
+                        pbegin(std::string("resize_nearest_") + dtn(), 0.0, 2.0 * B2 * th * tw * (double)co * es());
+                        const int st = resize_nearest(x.p, rz.p, B2, x.H, x.W, th, tw, (size_t)co * es(), s);
+                        pend();
+                        CK(st);
+                    }
+                    CK(conv3(rz, uw, (const float*)ub->p, nullptr, u.p, co, 1, 0));
+                }
                 x = u;
             }
         }
@@ -478,7 +496,8 @@ int tap_geometry(const dsim_unet_cfg& c, int* tokens, int* heads, int* hd) {
     const int depth = c.depth_per_level[level] > 0 ? c.depth_per_level[level] : 1;
     if (c.tap_tfm >= depth) return DSIM_ERR_INVALID;
     // spatial side at that level: one downsample per level except after the last
-    const int side = c.sample_size >> level;
+    int side = c.sample_size;
+    for (int l = 0; l < level; ++l) side = (side + 1) / 2;        // stride-2 convs: ceil (odd sides)
     const int C = c.block_out_channels[level];
     const int H = c.heads_per_level[level] > 0 ? c.heads_per_level[level] : c.num_heads;
     *tokens = side * side;
@@ -729,8 +748,7 @@ int dsim_unet_set_fusion(dsim_unet* h, int mask) {
 }
 
 int dsim_unet_set_sample_size(dsim_unet* h, int side) {
-    if (!h || side < 1) return DSIM_ERR_INVALID;
-    if (side % (1 << (h->cfg.n_levels - 1))) return DSIM_ERR_INVALID;
+    if (!h || side < 2) return DSIM_ERR_INVALID;          // any side: odd levels take the ceil-div / explicit-size path
     h->cfg.sample_size = side;
     return DSIM_OK;
 }

@@ -139,11 +139,10 @@ class UNetEngine:
     def set_sample_size(self, side: int):
         """Latent side of the next qkv() calls (cfg.sample_size is the default, not a limit)."""
         if side != self.sample_size:
-            m = 1 << (len(self.cfg.block_out_channels) - 1)
-            if side < m or side % m:
-                raise ValueError(f"latent side {side} (--image_size {8 * side}) must be a multiple of {m}, i.e. --image_size a "
-                                 f"multiple of {8 * m}: this engine has no ragged down/up-sampling path (diffusers' "
-                                 f"forward_upsample_size), so e.g. 224 px is refused rather than silently resized")
+            # any side the reference accepts (--image_size a multiple of 8, argprocess.py:8): sides that are not a multiple of
+            # 2**(levels-1) take the ceil-div stride-2 convs and the explicit-size upsample (diffusers' forward_upsample_size)
+            if side < 2:
+                raise ValueError(f"latent side {side}: --image_size must be at least 16")
             _lib.check(self.L.dsim_unet_set_sample_size(self._h, int(side)), "dsim_unet_set_sample_size")
             self.sample_size = int(side)
             self._refresh_tap_shape()

@@ -207,7 +207,11 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, padding=1)
 
     def forward(self, x, output_size=None):
-        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+        # [EXT] diffusers 0.29.2 Upsample2D.forward: nearest x2, or nearest to an explicit size when the U-Net passes
+        # upsample_size (latent sides that are not a multiple of 2**num_upsamplers, e.g. --image_size 224 -> 28 -> 14 -> 7 -> 4)
+        if output_size is None:
+            return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+        return self.conv(F.interpolate(x, size=output_size, mode="nearest"))
 
 
 class Attention(nn.Module):
@@ -446,14 +450,14 @@ class UpBlock2D(nn.Module):
         self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_upsample else None
         self.has_cross_attention = False
 
-    def forward(self, h, skips, temb, ctx=None):
+    def forward(self, h, skips, temb, ctx=None, upsample_size=None):
         for res in self.resnets:
             s = skips[-1]
             skips = skips[:-1]
             h = res(torch.cat([h, s], dim=1), temb)
         if self.upsamplers is not None:
             for u in self.upsamplers:
-                h = u(h)
+                h = u(h, upsample_size)
         return h
 
 
@@ -472,7 +476,7 @@ class CrossAttnUpBlock2D(nn.Module):
         self.gradient_checkpointing = False
         self.use_ipa = False
 
-    def forward(self, h, skips, temb, ctx):
+    def forward(self, h, skips, temb, ctx, upsample_size=None):
         for res, attn in zip(self.resnets, self.attentions):
             s = skips[-1]
             skips = skips[:-1]
@@ -480,7 +484,7 @@ class CrossAttnUpBlock2D(nn.Module):
             h = attn(h, encoder_hidden_states=ctx)[0]
         if self.upsamplers is not None:
             for u in self.upsamplers:
-                h = u(h)
+                h = u(h, upsample_size)              # hacked_modules.py:531-533
         return h
 
 
@@ -559,10 +563,15 @@ class UNet2DConditionModel(nn.Module):
             _rec(stats, f"down{i}", h)
         h = self.mid_block(h, temb, ctx)
         _rec(stats, "mid", h)
+        # [EXT] UNet2DConditionModel.forward: a latent side that is not a multiple of 2**num_upsamplers makes every
+        # non-final up block upsample to the size of the next skip instead of by 2 (forward_upsample_size)
+        up_factor = 2 ** (len(self.up_blocks) - 1)
+        forward_upsample_size = any(d % up_factor for d in sample.shape[-2:])
         for i, blk in enumerate(self.up_blocks):
             n = len(blk.resnets)
             s, skips = skips[-n:], skips[:-n]
-            h = blk(h, s, temb, ctx)
+            size = tuple(skips[-1].shape[2:]) if (forward_upsample_size and i != len(self.up_blocks) - 1) else None
+            h = blk(h, s, temb, ctx, upsample_size=size)
             _rec(stats, f"up{i}", h)
         h = self.conv_out(F.silu(self.conv_norm_out(h)))
         return h

@@ -157,3 +157,35 @@ def test_sd15_full_size_checkpoint_like_statistics():
         got = _scorer(cfg, sd, dtype).score_latent_pairs(zA, zB, n[2], n[3], ctx).cpu()
         assert torch.isfinite(got).all(), dtype
         assert abs(float(got) - want) <= bound, (dtype, float(got), want)
+
+
+@pytest.mark.parametrize("side", [14, 9, 28])
+def test_ragged_latent_sides_match_the_oracle(tiny_env, side):
+    """Latent sides that are not a multiple of 2**(levels-1) -- the reference accepts any --image_size (argprocess.py:8;
+    224 px -> 28 -> 14 -> 7 -> 4): stride-2 convs take ceil(H / 2) rows and every non-final up block upsamples to the size of
+    the next skip (nearest, explicit size: diffusers' forward_upsample_size, hacked_modules.py:531-533) instead of by 2.
+    fp32 kernel mode against the oracle at the north_star tolerance for taps on the down path, at the odd mid level and on
+    the up path behind an explicit-size upsample; the bf16 mode within its bound."""
+    R, unet, ctx = tiny_env["R"], tiny_env["oracle"], tiny_env["ctx"]
+    g = torch.Generator("cpu").manual_seed(100 + side)
+    zA, zB = (torch.randn((1, 4, side, side), generator=g) for _ in range(2))
+    nA, nB = (torch.randn((1, 4, side, side), generator=g) for _ in range(2))
+    ds = _scorer(C.TINY, tiny_env["sd"], torch.float32)
+    db = _scorer(C.TINY, tiny_env["sd"], torch.bfloat16)
+    for block, layer in (("down_blocks", 1), ("mid_blocks", 0), ("up_blocks", 0), ("up_blocks", 1), ("up_blocks", 2)):
+        so = float(R.diffsim_latents(unet, zA, zB, nA, nB, ctx, 600, block, layer, "cosine"))
+        s = float(ds.diffsim_latents(zA, zB, nA, nB, ctx, block, layer, 600, "cosine").cpu())
+        assert abs(s - so) <= 1e-4 * max(abs(so), 1e-6), (side, block, layer, s, so)
+        sb = float(db.diffsim_latents(zA, zB, nA, nB, ctx, block, layer, 600, "cosine").cpu())
+        assert abs(sb - so) <= 3e-2, (side, block, layer, sb, so)
+    # token counts follow the ceil-div pyramid
+    lv = [side]
+    for _ in range(3):
+        lv.append((lv[-1] + 1) // 2)
+    eng = ds.engine("up_blocks", 1)          # the second attention-bearing up block: resolution level 1
+    eng.set_sample_size(side)
+    assert eng.tokens == lv[1] ** 2
+    # batch-of-N == N singles at a ragged size too
+    z2A, z2B = torch.cat([zA, zB]), torch.cat([zB, zA])
+    both = db.score_latent_pairs(z2A, z2B, nA, nB, ctx, "up_blocks", 2, 600, "cosine")
+    assert torch.equal(both[0], db.score_latent_pairs(zA, zB, nA, nB, ctx, "up_blocks", 2, 600, "cosine")[0])

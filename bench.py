@@ -42,6 +42,9 @@ TAP_KEYS_EXCLUDE = ("up_blocks.2", "up_blocks.3", "conv_norm_out", "conv_out")
 # kernel family (dsim_*_profile_get) -> symbol rocprofv3 --kernel-trace prints
 def rocprof_name(fam: str) -> str:
     p = fam.split("_")
+    if p[0] == "gemm" and p[1] == "small":           # gemm_small_<dt>_<bm>x<bn>_<mode>[_res]: the small-batch kernel (gemm_skinny.hip)
+        bm, bn = p[3].split("x")
+        return f"gemm_skinny_kernel<{'1' if p[4] == 'conv3' else '0'}, {'true' if fam.endswith('_res') else 'false'}, {bm}, {bn}>"
     if p[0] == "gemm":
         t = {"bf16": "__bf16", "f16": "_Float16"}.get(p[1], "float")
         bm, bn = p[2].split("x")

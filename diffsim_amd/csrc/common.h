@@ -11,6 +11,10 @@
 #define launch_gemm launch_gemm_f16
 #define gemm_tile_choice gemm_tile_choice_f16
 #define gemm_band_width gemm_band_width_f16
+#define gemm_fill_extents gemm_fill_extents_f16
+#define gemm_skinny_applies gemm_skinny_applies_f16
+#define gemm_skinny_tile gemm_skinny_tile_f16
+#define launch_gemm_skinny launch_gemm_skinny_f16
 #define cu_count cu_count_f16
 #define rowlin_stream_bytes rowlin_stream_bytes_f16
 #define pack_rowlin_stream pack_rowlin_stream_f16
@@ -138,6 +142,8 @@ int launch_gemm(const GemmArgs& a, int dtype, hipStream_t s);
 extern int g_gemm_persistent;   // 0 = one tile per workgroup
 extern int g_force_bm;          // 0 = heuristic; 128/256 force the row tile
 extern int g_gemm_exp;          // experiment mask passed to gemm_kernel
+extern int g_gemm_skinny;       // 0 = small problems through gemm_kernel as well
+extern int g_skinny_tile;       // 0 = heuristic, else (bm << 8) | bn
 extern int g_gn_onepass;        // DSIM_GN_ONEPASS
 extern int g_ln_rows;           // DSIM_LN_ROWS
 extern int g_prep8;             // DSIM_PREP8
@@ -148,8 +154,12 @@ extern int g_ff_dbg;            // ablation mask of the fused feed-forward kerne
 extern int g_rl_dbg;            // ablation mask of the row-resident Linear kernel (rowres.hip)
 extern int g_ff_stagger;        // its wave de-phasing, in s_nop 7 units per wave index
 #else
-constexpr int g_gemm_persistent = 1, g_force_bm = 0, g_gn_onepass = 1, g_ln_rows = 1, g_prep8 = 1, g_attn_q2 = 1, g_attn_short = 1;
+constexpr int g_gemm_skinny = 1, g_gemm_persistent = 1, g_force_bm = 0, g_gn_onepass = 1, g_ln_rows = 1, g_prep8 = 1, g_attn_q2 = 1, g_attn_short = 1;
 #endif
+int gemm_fill_extents(GemmArgs& g, size_t es);                       // operand byte extents for the buffer descriptors
+bool gemm_skinny_applies(const GemmArgs& a);                         // small-batch kernel (gemm_skinny.hip): same arithmetic, deep ring
+int launch_gemm_skinny(const GemmArgs& g /*extents filled*/, hipStream_t s);
+void gemm_skinny_tile(const GemmArgs& a, int* bm, int* bn);          // its tile for this problem
 int gemm_band_width(int tilesM, int tilesN, size_t w_tile_bytes);   // tile-order band width (L2 reuse of the weight tiles)
 void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn);   // which template instantiation launch_gemm picks
 

@@ -30,6 +30,7 @@ namespace dsim {
 int g_force_bm = 0;
 int g_gemm_persistent = 1;
 int g_gemm_exp = 0;
+int g_gemm_skinny = 1;
 #endif
 // Tile choice.  Small problems: 128-row tiles, 4 waves, two workgroups per CU (160-wide when N
 // allows -- every SD channel count is a multiple of 160 -- else 128).  h16 problems with enough
@@ -592,6 +593,23 @@ int gemm_band_width(int tilesM, int tilesN, size_t w_tile_bytes) {
     return even < gn ? even : gn;
 }
 
+// byte extents of the operands for the buffer descriptors (32-bit offsets: every tensor < 2 GiB)
+int gemm_fill_extents(GemmArgs& g, size_t es) {
+    size_t a0b, a1b = 16;
+    if (g.mode == GEMM_CONV3) {
+        const size_t bimg = (size_t)g.M / ((size_t)g.Hout * g.Wout);
+        a0b = bimg * g.Hin * g.Win * g.C0 * es;
+    } else {
+        a0b = (size_t)g.M * g.C0 * es;
+        if (g.A1) a1b = (size_t)g.M * g.C1 * es;
+    }
+    const size_t wb = (size_t)g.N * g.K * es;
+    const size_t ob = (size_t)g.M * g.ldo * es;        // output (and residual) extent: rows are ldo elements apart
+    if (a0b >= 0x7fffffffull || a1b >= 0x7fffffffull || wb >= 0x7fffffffull || ob >= 0x7fffffffull) return DSIM_ERR_INVALID;
+    g.a0_bytes = (unsigned)a0b; g.a1_bytes = (unsigned)a1b; g.w_bytes = (unsigned)wb; g.out_bytes = (unsigned)ob;
+    return DSIM_OK;
+}
+
 namespace {
 
 template <typename T, int BM, int BN, int MODE, bool GEGLU, int WM, int WN, int EK>
@@ -603,21 +621,12 @@ int launch_ek(const GemmArgs& a, hipStream_t s) {
     auto kern = gemm_kernel<T, BM, BN, MODE, GEGLU, WM, WN, EK>;
     CK_ONCE(once, kern, LDS);
     const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
-    // byte extents of the three operands for the buffer descriptors (32-bit offsets: < 2 GiB each)
     GemmArgs g = a;
     const size_t es = sizeof(T);
-    size_t a0b, a1b = 16;
-    if (MODE == GEMM_CONV3) {
-        const size_t bimg = (size_t)a.M / ((size_t)a.Hout * a.Wout);
-        a0b = bimg * a.Hin * a.Win * a.C0 * es;
-    } else {
-        a0b = (size_t)a.M * a.C0 * es;
-        if (a.A1) a1b = (size_t)a.M * a.C1 * es;
+    {
+        const int st = gemm_fill_extents(g, es);
+        if (st != DSIM_OK) return st;
     }
-    const size_t wb = (size_t)a.N * a.K * es;
-    const size_t ob = (size_t)a.M * a.ldo * es;        // output (and residual) extent: rows are ldo elements apart
-    if (a0b >= 0x7fffffffull || a1b >= 0x7fffffffull || wb >= 0x7fffffffull || ob >= 0x7fffffffull) return DSIM_ERR_INVALID;
-    g.a0_bytes = (unsigned)a0b; g.a1_bytes = (unsigned)a1b; g.w_bytes = (unsigned)wb; g.out_bytes = (unsigned)ob;
 #ifdef DSIM_DEVTOOLS
     g.exp = g_gemm_exp;
 #endif
@@ -661,6 +670,14 @@ template <typename T>
 int launch_typed(const GemmArgs& a, hipStream_t s) {
     const int st = check_args(a, Traits<T>::BK);
     if (st != DSIM_OK) return st;
+    if constexpr (sizeof(T) == 2) {
+        // problems too small to fill the chip: 64 x 64 tiles behind a deep LDS ring, the same arithmetic bit for bit (gemm_skinny.hip)
+        if (g_gemm_skinny && gemm_skinny_applies(a)) {
+            GemmArgs g = a;
+            const int se = gemm_fill_extents(g, sizeof(T));
+            return se != DSIM_OK ? se : launch_gemm_skinny(g, s);
+        }
+    }
     int bm, bn;
     gemm_tile_choice(a, &bm, &bn);
     const bool slow = a.act != 0 || a.gate != nullptr;     // DiT linears only

@@ -81,7 +81,9 @@ struct Walk {
         if (h->profiling) {
             int bm, bn;
             gemm_tile_choice(g, &bm, &bn);
-            const std::string nm = std::string("gemm_") + dtn() + "_" + std::to_string(bm) + "x" + std::to_string(bn) +
+            const bool skinny = h->dt != DSIM_F32 && gemm_skinny_applies(g);      // the small-batch kernel (gemm_skinny.hip)
+            if (skinny) gemm_skinny_tile(g, &bm, &bn);
+            const std::string nm = std::string(skinny ? "gemm_small_" : "gemm_") + dtn() + "_" + std::to_string(bm) + "x" + std::to_string(bn) +
                                    (g.mode == GEMM_CONV3 ? "_conv3" : "_linear") +
                                    (g.epi == EPI_GEGLU ? "_geglu" : (g.epi == EPI_RESIDUAL ? "_res" : ""));   // one family per kernel symbol
             const double e = (double)es();

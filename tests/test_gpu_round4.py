@@ -189,3 +189,54 @@ def test_ragged_latent_sides_match_the_oracle(tiny_env, side):
     z2A, z2B = torch.cat([zA, zB]), torch.cat([zB, zA])
     both = db.score_latent_pairs(z2A, z2B, nA, nB, ctx, "up_blocks", 2, 600, "cosine")
     assert torch.equal(both[0], db.score_latent_pairs(zA, zB, nA, nB, ctx, "up_blocks", 2, 600, "cosine")[0])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_small_batch_gemm_is_bit_identical_to_the_large_batch_path(dtype):
+    """Problems too small to fill the chip run on 64 x 64 tiles behind an 8-slot LDS ring (csrc/gemm_skinny.hip) instead of
+    gemm_kernel's 128-row tiles.  The per-element arithmetic is the same MFMA sequence with the same rounding points, so a row
+    computed in a small batch equals, bit for bit, the same row computed inside a large batch (which takes gemm_kernel):
+    3x3 convs (plain, + residual, stride 2, folded x2 upsample), linears (plain, + bias, + residual), ragged M and N edges --
+    and both agree with fp32 torch on the CPU."""
+    import torch.nn.functional as F
+    from diffsim_amd import engine as E
+    g = torch.Generator().manual_seed(11)
+    rt = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    # ---- convs: 3 images alone (M = 3 * 64 = 192 rows at 8 x 8) vs the same 3 images first in a batch of 96
+    for Cin, Cout, stride, ups, res in ((320, 320, 1, False, False), (640, 1280, 1, False, True), (128, 192, 2, False, False),
+                                        (256, 128, 1, True, True), (1280, 1280, 1, False, True)):
+        H = 8
+        xs = torch.randn(96, H, H, Cin, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+        b = torch.randn(Cout, generator=g)
+        Ho = 2 * H if ups else (H // 2 if stride == 2 else H)
+        r = torch.randn(96, Ho, Ho, Cout, generator=g) if res else None
+        xd, wd, bd = xs.cuda().to(dtype), w.cuda(), b.cuda()
+        rd = r.cuda().to(dtype) if res else None
+        small = E.op_conv3x3(xd[:3].contiguous(), wd, bd, rd[:3].contiguous() if res else None, stride, ups)
+        big = E.op_conv3x3(xd, wd, bd, rd, stride, ups)
+        assert torch.equal(small, big[:3]), (Cin, Cout, stride, ups, res)
+        xin = xd[:3].float().cpu().permute(0, 3, 1, 2)
+        if ups:
+            xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+        want = F.conv2d(xin, w, b, stride=stride, padding=1).permute(0, 2, 3, 1)
+        if res:
+            want = want + rd[:3].float().cpu()
+        assert (small.float().cpu() - want).abs().max().item() <= rt * float(want.abs().max())
+    # ---- linears: 200 rows alone vs the same rows first among 40000
+    for K, N, res, bias in ((1280, 1280, True, True), (640, 1920, False, False), (2560, 640, True, True), (768, 2560, False, True),
+                            (1280, 328, False, True)):
+        x = torch.randn(40000, K, generator=g)
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g) if bias else None
+        r = torch.randn(40000, N, generator=g) if res else None
+        xd, wd = x.cuda().to(dtype), w.cuda()
+        bd = b.cuda() if bias else None
+        rd = r.cuda().to(dtype) if res else None
+        small = E.op_linear(xd[:200].contiguous(), wd, bd, rd[:200].contiguous() if res else None)
+        big = E.op_linear(xd, wd, bd, rd)
+        assert torch.equal(small, big[:200]), (K, N, res, bias)
+        want = xd[:200].float().cpu() @ w.T + (b if bias else 0.0)
+        if res:
+            want = want + rd[:200].float().cpu()
+        assert (small.float().cpu() - want).abs().max().item() <= rt * float(want.abs().max())

@@ -57,11 +57,14 @@ def rocprof_name(fam: str) -> str:
     if p[0] == "attention":
         if p[1] == "fp8":
             return f"attn_fp8_kernel<{p[2][1:]}>"
-        if fam == "attention_bf16_d40_long":         # the 4096-key level of SD1.5: the pipelined two-query-block kernel
-            return "attn_long_kernel<40, 0>"
-        if fam == "attention_bf16_d40":              # what is left of d = 40: the 77-key cross-attentions (short-key kernel)
-            return "attn_short_kernel<40>"
-        return f"attn_kernel<{'__bf16' if p[1] == 'bf16' else 'float'}, {p[2][1:]}, {'true' if fam.endswith('_long') else 'false'}>"
+        t = {"bf16": "__bf16", "f16": "_Float16"}.get(p[1], "float")
+        d = p[2][1:]
+        kind = p[3] if len(p) > 3 else ""              # the suffix csrc/attention.hip attention_kernel_kind() gave the family
+        if kind == "short":
+            return f"attn_short_kernel<{d}>"
+        if kind == "long":
+            return f"attn_long_kernel<{d}, 0>"
+        return f"attn_kernel<{t}, {d}, {'true' if kind == 'fast' else 'false'}>"
     if p[0] == "ff":
         return "ff_fused_kernel<0>"
     if p[0] == "ln" and p[1] == "linear":
@@ -397,7 +400,7 @@ def headline(a, world, rank, dev):
     # A step scores NS independent sub-batches of bp pairs, each enqueued on its own HIP stream: the HBM-bound kernels of
     # one sub-batch (norms) run under the MFMA-bound kernels of the other (profiles/r02_two_stream.txt)
     NS = 1 if a.pixels_in else max(1, a.streams)
-    qkvs = [tuple(torch.empty(shape, dtype=dtype, device=dev) for _ in range(3)) for _ in range(NS)]
+    qkvs = [tuple(torch.empty((3,) + shape, dtype=dtype, device=dev).unbind(0)) for _ in range(NS)]     # (one allocation: the tap's q|k|v is one launch)
     qkv = qkvs[0]
     side = [torch.cuda.Stream(device=dev) for _ in range(NS)] if NS > 1 else []
 
@@ -525,7 +528,9 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
+        from diffsim_amd.parallel import pin_to_gpu_numa
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        pin_to_gpu_numa(local)             # host threads (weight synthesis, launches) on the cores next to this rank's GPU
         # every rank builds the same synthetic weights on the host: share the cores instead of oversubscribing them
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
         dist.init_process_group("nccl", device_id=dev)

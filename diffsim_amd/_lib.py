@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(HERE, "libdiffsim_amd.so")
 DSIM_F32, DSIM_BF16, DSIM_F16 = 0, 1, 2
 TAP = {"down_blocks": 0, "mid_blocks": 1, "up_blocks": 2}
 MAX_LEVELS = 4
-FUSE_FF, FUSE_LNPROJ, FUSE_ALL = 1, 2, 3        # dsim_unet_set_fusion bits
+FUSE_FF, FUSE_LNPROJ, FUSE_TAPQKV, FUSE_ALL = 1, 2, 4, 7        # dsim_unet_set_fusion bits
 
 
 class DsimError(RuntimeError):

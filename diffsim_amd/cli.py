@@ -213,9 +213,18 @@ def run(args) -> int:
 def main(argv=None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
     args = arg_parse(argv)
-    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.ngpu:
-        raise SystemExit(f"--ngpu {args.ngpu} but WORLD_SIZE={os.environ['WORLD_SIZE']}: refusing to run a mislabelled launch "
-                         f"(pass --ngpu equal to the number of ranks the launcher started)")
+    if "WORLD_SIZE" in os.environ:
+        # --ngpu counts the GPUs of THIS node: under a launcher that is LOCAL_WORLD_SIZE (WORLD_SIZE on one node).  A launch
+        # that left --ngpu at its default adopts the launcher's count; an explicit, different --ngpu is refused as mislabelled.
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"]))
+        explicit = any(a == "--ngpu" or a.startswith("--ngpu=") for a in argv)
+        if not explicit:
+            if local_world != args.ngpu:
+                print(f"diffsim_amd: --ngpu not given; using the launcher's {local_world} rank(s) on this node", file=sys.stderr)
+            args.ngpu = local_world
+        elif local_world != args.ngpu:
+            raise SystemExit(f"--ngpu {args.ngpu} but the launcher started {local_world} rank(s) on this node "
+                             f"(LOCAL_WORLD_SIZE / WORLD_SIZE): refusing to run a mislabelled launch")
     if args.ngpu > 1 and "WORLD_SIZE" not in os.environ:
         from .parallel import spawn_ranks              # the parent never touches the GPU
         return spawn_ranks(args.ngpu, [sys.executable, "-m", "diffsim_amd"] + argv)

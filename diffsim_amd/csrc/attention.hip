@@ -1121,6 +1121,18 @@ int g_attn_dbg = 0;
 int g_attn_short = 1;
 #endif
 
+// Which kernel launch_attention picks for this problem, as the suffix of the profile family name (bench.py maps family names to
+// the symbols rocprofv3 prints): "_short" attn_short_kernel (keys resident in LDS), "_long" attn_long_kernel (two query blocks
+// per wave, pipelined), "_fast" attn_kernel with the fixed-reference softmax, "" attn_kernel with the exact running maximum.
+// Mirrors launch_attn_d's conditions (the development switches are 1 in the product).
+const char* attention_kernel_kind(const AttnArgs& a, int dtype) {
+    if (dtype == DSIM_F32) return "";
+    if ((a.D == 40 || a.D == 80) && a.Nk <= 96) return "_short";
+    if (a.D == 40 && a.Nk >= 2048 && a.Nk % KT == 0) return "_long";
+    if (a.Nk >= 2048) return "_fast";
+    return "";
+}
+
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
     const int vec = dtype == DSIM_F32 ? 4 : 8;
     if (a.D % 8 || a.ldq % vec || a.ldk % vec || a.ldo % 4 || a.Nk < 1 || a.Nq < 1 || a.Bkv < 1)

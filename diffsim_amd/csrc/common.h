@@ -26,6 +26,7 @@
 #define launch_layernorm_mod launch_layernorm_mod_f16
 #define launch_softmax_rows launch_softmax_rows_f16
 #define launch_attention launch_attention_f16
+#define attention_kernel_kind attention_kernel_kind_f16
 #define pair_score_scratch_bytes pair_score_scratch_bytes_f16
 #define launch_pair_score launch_pair_score_f16
 #define ff_stream_bytes ff_stream_bytes_f16
@@ -129,6 +130,8 @@ struct GemmArgs {
     const void* residual = nullptr;             // [M][ldo]
     void* out = nullptr;
     int ldo = 0;
+    int out_split = 0;                          // > 0 (plain linear only, % 320 == 0): output columns [j*split, (j+1)*split) go to the
+    long long out_split_stride = 0;             //   tensor at out + j * out_split_stride bytes, each [M][ldo] (the tapped q | k | v)
     const void* zero_page = nullptr;            // >= 16 zero bytes (kept for ABI stability; padding now comes from OOB buffer reads)
     unsigned a0_bytes = 0, a1_bytes = 0, w_bytes = 0, out_bytes = 0;   // filled by launch_gemm: operand extents for the buffer descriptors
 #ifdef DSIM_DEVTOOLS
@@ -235,6 +238,7 @@ struct AttnArgs {
     int xcd_remap = 1;                        // 0: plain block order (micro-benchmark A/B only)
 };
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t s);
+const char* attention_kernel_kind(const AttnArgs& a, int dtype);      // "_short" / "_long" / "_fast" / "": the kernel it picks
 int launch_attention_fp8(const AttnArgs& a, hipStream_t s);      // h16 in/out, e4m3 MFMAs (attention_fp8.hip)
 size_t pair_score_scratch_bytes(int n_pairs, int B, int H, int N, int D);
 int launch_pair_score(const void* q, const void* k, const void* v, const int32_t* idx_a,

@@ -187,7 +187,8 @@ struct DWalk {
                 a.q = big; a.ldq = 3 * D;
                 a.k = (char*)big + (size_t)D * es(); a.v = (char*)big + (size_t)2 * D * es(); a.ldk = 3 * D;
                 a.out = ab; a.ldo = D; a.B = n * 2; a.Bkv = n * 2; a.H = H; a.Nq = T; a.Nk = T; a.D = D / H;
-                pbegin(std::string(h->attn_mode == 1 ? "attention_fp8_d" : "attention_bf16_d") + std::to_string(a.D) + "|B" +
+                pbegin((h->attn_mode == 1 ? std::string("attention_fp8_d") + std::to_string(a.D)
+                                           : std::string("attention_") + dtn() + "_d" + std::to_string(a.D) + attention_kernel_kind(a, h->dt)) + "|B" +
                            std::to_string(a.B) + " H" + std::to_string(H) + " Nq" + std::to_string(T) + " Nk" + std::to_string(T),
                        4.0 * a.B * H * (double)T * T * a.D, (double)es() * a.B * H * a.D * 4.0 * T);
                 const int st = h->attn_mode == 1 ? launch_attention_fp8(a, s) : launch_attention(a, h->dt, s);

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     constexpr int OUTW = GEGLU ? WBN / 2 : WBN;        // output columns this wave produces
     constexpr int RSO = OUTW * ES + 16;                 // staging row stride (bytes)
     constexpr int CPR = OUTW * ES / 16;                 // 16-byte chunks per output row
-    const int Nout = GEGLU ? (p.N >> 1) : p.N;
+    const int Nout = GEGLU ? (p.N >> 1) : (p.out_split ? p.out_split : p.N);
     typedef typename Vec16T<T>::type V16;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int NIT = (16 * CPR + 63) / 64;          // read-back iterations per 16-row slab
@@ -420,7 +420,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
         const int el15 = elane & 15, equad = elane >> 4;
         char* const wst = smem + (xbuf ? STAGE : 0) + wave * (16 * RSO);
         const int nw0 = en0 + wn * WBN;                    // first packed weight row of this wave
-        const int nout0 = GEGLU ? (nw0 >> 1) : nw0;
+        // out_split: the output columns are cut into equal runs that go to separate tensors (the tapped q | k | v projection as one
+        // launch): tensor en0 / split, column en0 % split; BN divides the split, so a tile never straddles two tensors.  The
+        // store descriptor is rebuilt per tile with the tensor's base (plain projection epilogue only: no residual, no GEGLU).
+        int osel = 0;
+        if (!GEGLU && EK == EK_PLAIN && MODE == GEMM_LINEAR && p.out_split) osel = __builtin_amdgcn_readfirstlane(en0 / p.out_split);
+        const __amdgpu_buffer_rsrc_t rOt = (!GEGLU && EK == EK_PLAIN && MODE == GEMM_LINEAR)
+            ? __builtin_amdgcn_make_buffer_rsrc((char*)p.out + (size_t)osel * p.out_split_stride, 0, (int)p.out_bytes, 0x00020000) : rO;
+        const int nout0 = (GEGLU ? (nw0 >> 1) : nw0) - osel * p.out_split;
         const int mw0 = em0 + wm * (BM / WM);
         // byte offset of read-back piece `it` of slab i in the output (and residual) tensor; out-of-range
         // rows / columns get an out-of-bounds buffer offset: loads return 0, stores are dropped -- no branches
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                 const int rrow = row < 16 ? row : 15;
                 const V16 t = *reinterpret_cast<const V16*>(wst + rrow * RSO + c * 16);
                 if (!SLOW && !ACT && !has_res) {         // plain projection: LDS -> HBM copy
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rO, (int)off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rOt, (int)off, 0, 0);
                     continue;
                 }
                 float v[VEC];
@@ -663,6 +670,9 @@ int check_args(const GemmArgs& a, int BK) {
     }
     if (a.epi == EPI_GEGLU && (a.mode != GEMM_LINEAR || a.N % 64)) return DSIM_ERR_INVALID;
     if (!a.zero_page) return DSIM_ERR_INVALID;
+    if (a.out_split && (a.mode != GEMM_LINEAR || a.epi != EPI_NONE || a.act || a.gate || a.out_split % 320 || a.N % a.out_split ||
+                        a.out_split_stride <= 0 || (a.N / a.out_split) * a.out_split_stride >= 0x7fffffffll))
+        return DSIM_ERR_INVALID;
     return DSIM_OK;
 }
 

@@ -230,7 +230,7 @@ void gemm_skinny_tile(const GemmArgs& a, int* bm, int* bn) {
 // tiles) would occupy at most a quarter of the CUs (at half, gemm_kernel is as fast or faster: 4096 x 640), with a K loop long
 // enough for the ring to matter.
 bool gemm_skinny_applies(const GemmArgs& a) {
-    if (a.epi == EPI_GEGLU || a.act != 0 || a.gate != nullptr) return false;
+    if (a.epi == EPI_GEGLU || a.act != 0 || a.gate != nullptr || a.out_split) return false;
     if (a.K < 8 * 64 || a.K % 64 || a.C0 % 64 || (a.A1 && a.C1 % 64) || a.N % 8) return false;
     const long reg_tiles = (long)((a.M + 127) / 128) * ((a.N + 159) / 160);
     return reg_tiles * 4 <= cu_count();

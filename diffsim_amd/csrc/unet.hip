@@ -149,7 +149,7 @@ struct Walk {
     int attn(const AttnArgs& a) {
         if (!run) return DSIM_OK;
         // (key sequences >= 2048 run the fixed-reference instantiation attn_kernel<T, D, true>: its own family)
-        pbegin(std::string("attention_") + dtn() + "_d" + std::to_string(a.D) + (a.Nk >= 2048 && h->dt != DSIM_F32 ? "_long" : "") +
+        pbegin(std::string("attention_") + dtn() + "_d" + std::to_string(a.D) + attention_kernel_kind(a, h->dt) +
                    "|B" + std::to_string(a.B) + " H" + std::to_string(a.H) +
                    " Nq" + std::to_string(a.Nq) + " Nk" + std::to_string(a.Nk),
                4.0 * a.B * a.H * (double)a.Nq * a.Nk * a.D,
@@ -268,9 +268,20 @@ struct Walk {
             Packed wq = *qkv, wk = *qkv, wv = *qkv;
             wk.p = (char*)qkv->p + (size_t)C * C * es();
             wv.p = (char*)qkv->p + (size_t)2 * C * C * es();
-            CK(linear(nb, C, nullptr, 0, &wq, nullptr, nullptr, q_out, M, C, C));
-            CK(linear(nb, C, nullptr, 0, &wk, nullptr, nullptr, k_out, M, C, C));
-            CK(linear(nb, C, nullptr, 0, &wv, nullptr, nullptr, v_out, M, C, C));
+            // one launch when q, k, v lie at equal distances (engine.py allocates them as one [3][...] buffer) and the width
+            // tiles by 320: the packed [3C][C] weight as one N = 3C GEMM whose column runs go to the three tensors
+            const long long qk = (const char*)k_out - (const char*)q_out, kv = (const char*)v_out - (const char*)k_out;
+            const bool bm_split = C % 320 == 0;
+            if ((h->fusion & DSIM_FUSE_TAPQKV) && qk == kv && qk >= (long long)M * C * (long long)es() && 3 * qk < 0x7fffffffll && bm_split) {
+                GemmArgs g;
+                g.A0 = nb; g.C0 = C; g.mode = GEMM_LINEAR; g.M = M; g.N = 3 * C; g.K = C;
+                g.W = qkv->p; g.epi = EPI_NONE; g.out = q_out; g.ldo = C; g.out_split = C; g.out_split_stride = qk;
+                CK(gemm(g));
+            } else {
+                CK(linear(nb, C, nullptr, 0, &wq, nullptr, nullptr, q_out, M, C, C));
+                CK(linear(nb, C, nullptr, 0, &wk, nullptr, nullptr, k_out, M, C, C));
+                CK(linear(nb, C, nullptr, 0, &wv, nullptr, nullptr, v_out, M, C, C));
+            }
             tapped = true;
             ar->release(mk);
             return DSIM_OK;

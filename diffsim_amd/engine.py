@@ -267,7 +267,7 @@ class UNetEngine:
             if self.use_graphs and out is None and not self._profiling:
                 return self._replay(latents, noise, float(sqrt_abar), float(sqrt_1m_abar), ctx, shape)
             if out is None:
-                out = tuple(torch.empty(shape, dtype=self.dtype, device=self.device) for _ in range(3))
+                out = tuple(torch.empty((3,) + tuple(shape), dtype=self.dtype, device=self.device).unbind(0))    # one allocation: the tapped q | k | v projection is then one launch
             self._launch(latents, noise, float(sqrt_abar), float(sqrt_1m_abar), ctx, out)
         return out
 
@@ -285,7 +285,7 @@ class UNetEngine:
         ent = self._graphs.get(key)
         if ent is None:
             st = {"lat": torch.empty_like(latents), "nz": torch.empty_like(noise), "ctx": torch.empty_like(ctx),
-                  "out": tuple(torch.empty(shape, dtype=self.dtype, device=self.device) for _ in range(3))}
+                  "out": tuple(torch.empty((3,) + tuple(shape), dtype=self.dtype, device=self.device).unbind(0))}
             st["lat"].copy_(latents), st["nz"].copy_(noise), st["ctx"].copy_(ctx)
             self._launch(st["lat"], st["nz"], sa, sb, st["ctx"], st["out"])      # eager warm-up (code objects loaded)
             torch.cuda.synchronize(self.device)

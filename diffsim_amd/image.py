@@ -43,7 +43,9 @@ def host_threads(world: int = 0) -> int:
     ranks of one node share the host (world = 0: read LOCAL_WORLD_SIZE / WORLD_SIZE), so that an 8-GPU node's eight
     ranks do not each start a full-width pool."""
     if world <= 0:
-        world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        # after parallel.pin_to_gpu_numa the affinity mask already is one NUMA node's cores: divide it by the ranks on that
+        # node, not by the whole local world a second time
+        world = int(os.environ.get("DSIM_RANKS_ON_THESE_CPUS", os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
     return max(4, min(64, n // max(1, world)))
 

@@ -109,10 +109,16 @@ def pin_to_gpu_numa(local_rank: int) -> bool:
             for part in f.read().strip().split(","):
                 lo, _, hi = part.partition("-")
                 cpus.update(range(int(lo), int(hi or lo) + 1))
-        cpus &= os.sched_getaffinity(0)
+        before = os.sched_getaffinity(0)
+        cpus &= before
         if not cpus:
             return False
         os.sched_setaffinity(0, cpus)
+        # the ranks of this host now share len(cpus) cores per NUMA node, not len(before) cores among all of them: tell the
+        # pool sizing (image.host_threads) how many ranks sit on THIS node's cores -- the local world scaled by the share of
+        # the host's cores this node holds (2 sockets x 4 GPUs: 8 ranks -> 4 per node)
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        os.environ["DSIM_RANKS_ON_THESE_CPUS"] = str(max(1, round(lw * len(cpus) / max(1, len(before)))))
         return True
     except Exception:
         return False

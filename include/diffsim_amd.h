@@ -154,10 +154,14 @@ int  dsim_unet_set_cfg_dedup(dsim_unet* h, int enable);
  * DSIM_FUSE_FF: norm3 -> ff.net.0.proj (GEGLU) -> ff.net.2 -> + residual of a 320-channel BasicTransformerBlock as one launch
  * (hacked_modules.py:118-132).
  * DSIM_FUSE_LNPROJ: the LayerNorm in front of a 320-channel block's self-attention q/k/v projection (norm1 -> to_q|to_k|to_v)
- * and of its cross-attention query (norm2 -> attn2.to_q) runs inside the projection's launch (hacked_modules.py:88-116). */
+ * and of its cross-attention query (norm2 -> attn2.to_q) runs inside the projection's launch (hacked_modules.py:88-116).
+ * DSIM_FUSE_TAPQKV: the tapped layer's to_q / to_k / to_v (hacked_attn.py:61-69) as ONE N = 3C launch whose column runs go to the
+ * three output tensors -- taken when q, k, v lie at equal distances in memory (one [3][...] allocation); bit-identical to the
+ * three launches, any compute dtype. */
 #define DSIM_FUSE_FF     1
 #define DSIM_FUSE_LNPROJ 2
-#define DSIM_FUSE_ALL    3
+#define DSIM_FUSE_TAPQKV 4
+#define DSIM_FUSE_ALL    7
 int  dsim_unet_set_fusion(dsim_unet* h, int mask);
 /* Latent side of the next dsim_unet_qkv calls (cfg.sample_size is only the default): the reference runs any
  * --image_size through the same weights (argprocess.py:8: default 512 px, SDXL native 1024 px).  `side` must be a

@@ -64,7 +64,38 @@ def write_stats(tag, trace):
                         r["MinNs"], r["MaxNs"]])
 
 
+def write_mfma(outname, d):
+    """profiles/<outname>.json: per kernel MFMA utilisation and held clock from a `--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` pass"""
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    rr = list(csv.DictReader(open(f)))
+    dm3 = demangle(sorted({r["Kernel_Name"] for r in rr}))
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in rr:
+        e = acc[short(dm3[r["Kernel_Name"]])]
+        e[r["Counter_Name"]] += float(r["Counter_Value"])
+        e["n_" + r["Counter_Name"]] += 1
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("End_Timestamp") and r.get("Start_Timestamp"):
+            e["ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    mf = {}
+    for k, e in acc.items():
+        n = max(e["n_GRBM_GUI_ACTIVE"], 1)
+        cyc = e["GRBM_GUI_ACTIVE"] / 8.0 / n
+        busy = e["SQ_VALU_MFMA_BUSY_CYCLES"] / max(e["n_SQ_VALU_MFMA_BUSY_CYCLES"], 1)
+        mf[k] = {"launches": int(n), "cycles_per_launch": int(cyc), "mfma_busy_cycles_per_launch": int(busy),
+                 "mfma_util": round(busy / (cyc * 1024.0), 4) if cyc else None}
+        if e.get("ns"):
+            # clock the chip held during this kernel IN THIS (profiled, serialised) pass: GRBM_GUI_ACTIVE / 8 XCDs over the
+            # dispatch's own begin/end timestamps (reads high on dispatches shorter than ~0.3 ms: MI355X_MICROARCH.md DVFS)
+            mf[k]["held_clock_ghz"] = round(e["GRBM_GUI_ACTIVE"] / 8.0 / e["ns"], 3)
+            mf[k]["avg_launch_us"] = round(e["ns"] / n / 1e3, 1)
+    json.dump(mf, open(os.path.join(HERE, f"{outname}.json"), "w"), indent=1, sort_keys=True)
+
+
 def main():
+    if sys.argv[1] == "--mfma-only":           # python profiles/summarize.py --mfma-only <output name> <mfma pass dir>
+        write_mfma(sys.argv[2], sys.argv[3])
+        print("wrote", sys.argv[2])
+        return
     if sys.argv[1] == "--stats-only":          # python profiles/summarize.py --stats-only <tag> <trace dir>
         write_stats(sys.argv[2], sys.argv[3])
         print("wrote", sys.argv[2])
@@ -90,28 +121,7 @@ def main():
                   "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024)}
     json.dump(out, open(os.path.join(HERE, f"{tag}_pmc_hbm.json"), "w"), indent=1, sort_keys=True)
     if len(sys.argv) > 5:
-        f = glob.glob(os.path.join(sys.argv[5], "**", "*counter_collection.csv"), recursive=True)[0]
-        rr = list(csv.DictReader(open(f)))
-        dm3 = demangle(sorted({r["Kernel_Name"] for r in rr}))
-        acc = collections.defaultdict(lambda: collections.defaultdict(float))
-        for r in rr:
-            e = acc[short(dm3[r["Kernel_Name"]])]
-            e[r["Counter_Name"]] += float(r["Counter_Value"])
-            e["n_" + r["Counter_Name"]] += 1
-            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("End_Timestamp") and r.get("Start_Timestamp"):
-                e["ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-        mf = {}
-        for k, e in acc.items():
-            n = max(e["n_GRBM_GUI_ACTIVE"], 1)
-            cyc = e["GRBM_GUI_ACTIVE"] / 8.0 / n
-            busy = e["SQ_VALU_MFMA_BUSY_CYCLES"] / max(e["n_SQ_VALU_MFMA_BUSY_CYCLES"], 1)
-            mf[k] = {"launches": int(n), "cycles_per_launch": int(cyc), "mfma_busy_cycles_per_launch": int(busy),
-                     "mfma_util": round(busy / (cyc * 1024.0), 4) if cyc else None}
-            if e.get("ns"):
-                # clock the chip held during this kernel IN THIS (profiled, serialised) pass: GRBM_GUI_ACTIVE / 8 XCDs over the
-                # dispatch's own begin/end timestamps (reads high on dispatches shorter than ~0.3 ms: MI355X_MICROARCH.md DVFS)
-                mf[k]["held_clock_ghz"] = round(e["GRBM_GUI_ACTIVE"] / 8.0 / e["ns"], 3)
-        json.dump(mf, open(os.path.join(HERE, f"{tag}_pmc_mfma.json"), "w"), indent=1, sort_keys=True)
+        write_mfma(f"{tag}_pmc_mfma", sys.argv[5])
     print("wrote", tag)
 
 

@@ -288,8 +288,9 @@ def test_fused_kernels_agree_with_their_unfused_chains():
     ef.profile(False); ep.profile(False)
     assert ff.count("ff_fused_bf16") == 2 and "ff_fused_bf16" not in fp
     assert ff.count("ln_linear_bf16") == 4 and "ln_linear_bf16" not in fp
-    # two blocks x ((LayerNorm + GEGLU GEMM + ff.net.2 -> one launch) + 2 x (LayerNorm + projection -> one launch))
-    assert len(fp) - len(ff) == 8
+    # two blocks x ((LayerNorm + GEGLU GEMM + ff.net.2 -> one launch) + 2 x (LayerNorm + projection -> one launch)), and the tapped
+    # layer's to_q / to_k / to_v as one launch instead of three (DSIM_FUSE_TAPQKV, round 4)
+    assert len(fp) - len(ff) == 8 + 2
     el = only_ln.engine("down_blocks", 1)
     el.profile(True)
     only_ln.score_latent_pairs(zA[:1], zB[:1], n[2], n[3], ctx, "down_blocks", 1, 600, "cosine")

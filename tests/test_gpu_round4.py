@@ -240,3 +240,35 @@ def test_small_batch_gemm_is_bit_identical_to_the_large_batch_path(dtype):
         if res:
             want = want + rd[:200].float().cpu()
         assert (small.float().cpu() - want).abs().max().item() <= rt * float(want.abs().max())
+
+
+def test_tapped_qkv_as_one_launch_is_bit_identical():
+    """DSIM_FUSE_TAPQKV: the tapped layer's to_q / to_k / to_v as one N = 3C launch writing three tensors (taken when q, k, v are
+    one allocation, as engine.qkv makes them) against the three separate launches: bit for bit, bf16 / fp16 / fp32, at a width
+    the 320-column tiles divide (SD1.5's tap, 1280) -- and the fallback to three launches when the caller's q, k, v are
+    separate tensors."""
+    from diffsim_amd import _lib
+    cfg = C.SD15
+    keys = [k for k in C.unet_param_shapes(cfg) if not k.startswith(("up_blocks.2", "up_blocks.3", "conv_norm_out", "conv_out"))]
+    sd = S.make_state_dict(cfg, seed=0, keys=keys)
+    ctx = S.make_context(cfg)
+    n = S.draw_pair_noise(2334, (1, 4, 64, 64))
+    zA, zB = S.make_pair_latents(cfg, 1)
+    lat, nz = torch.cat([zA, zB]), torch.cat([n[2], n[3]])
+    for dtype in (torch.bfloat16, torch.float16, torch.float32):
+        one = _scorer(cfg, sd, dtype)
+        three = _scorer(cfg, sd, dtype, fusion=_lib.FUSE_ALL & ~_lib.FUSE_TAPQKV)
+        q1, k1, v1 = one.features(lat, nz, ctx, "up_blocks", 0, 600)
+        q3, k3, v3 = three.features(lat, nz, ctx, "up_blocks", 0, 600)
+        assert q1.data_ptr() + q1.numel() * q1.element_size() == k1.data_ptr()          # one allocation
+        assert torch.equal(q1, q3) and torch.equal(k1, k3) and torch.equal(v1, v3), dtype
+        # separate output tensors: the engine falls back to three launches, same bits
+        eng = one.engine("up_blocks", 0)
+        sep = tuple(torch.empty_like(q1) for _ in range(3))
+        import diffsim_amd.scheduler as sched
+        t = sched.timestep_from_index(600)
+        eng.set_timestep(t)
+        sa, sb = sched.noise_coefficients(t)
+        qs, ks, vs = eng.qkv(lat.cuda(), nz.cuda(), sa, sb, ctx.cuda(), out=sep)
+        assert torch.equal(qs, q1) and torch.equal(ks, k1) and torch.equal(vs, v1), dtype
+        del one, three

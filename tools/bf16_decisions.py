@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""2AFC decision agreement of the bf16 path with the fp32 kernel mode (SURVEY.md section 8d parity gate: "bf16 mode reports
+"""2AFC decision agreement of the 16-bit paths (bf16, fp16) with the fp32 kernel mode (SURVEY.md section 8d parity gate: "bf16 mode reports
 max/mean error and 2AFC decision flips").  The fp32 mode is the one pinned to the CPU oracle at 1e-4 (tests/test_gpu_fullsize.py);
-this tool measures what the bf16 kernels do to the DECISIONS of a NIGHTS-style run (night_main.py:156-163: left wins when
+this tool measures what the bf16 and the fp16 kernels do to the DECISIONS of a NIGHTS-style run (night_main.py:156-163: left wins when
 s(ref,left) > s(ref,right)): N synthetic full-size triplets (SD1.5, 512 px latents, up_blocks[0], step 600, cosine), the two
 distortions of a triplet drawn at nearby strengths so that a good share of the margins is small.
 
-    python tools/bf16_decisions.py [N=1000] > profiles/r03_bf16_decisions.json
+    python tools/bf16_decisions.py [N=1000] > profiles/r04_decisions_16bit.json
 """
 import json
 import os
@@ -36,7 +36,7 @@ left = (1 - a * a).sqrt() * ref + a * torch.randn(shp, generator=g) * 0.9
 right = (1 - b * b).sqrt() * ref + b * torch.randn(shp, generator=g) * 0.9
 n = S.draw_pair_noise(2334, (1, 4, 64, 64))
 out = {}
-for name, dt, bt in (("fp32", torch.float32, 8), ("bf16", torch.bfloat16, 20)):
+for name, dt, bt in (("fp32", torch.float32, 8), ("bf16", torch.bfloat16, 20), ("fp16", torch.float16, 20)):
     ds = DiffSim(torch_dtype=dt, device="cuda", unet_config=cfg, state_dict=sd)
     t0 = time.perf_counter()
     sl, sr = H.score_latent_triplets(ds, ref.cuda(), left.cuda(), right.cuda(), n[2], n[3], ctx, "up_blocks", 0, 600, "cosine", bt)
@@ -45,19 +45,19 @@ for name, dt, bt in (("fp32", torch.float32, 8), ("bf16", torch.bfloat16, 20)):
     del ds
     torch.cuda.empty_cache()
 fl, fr, tf = out["fp32"]
-bl, br, tb = out["bf16"]
-m32, m16 = fl - fr, bl - br                           # decision margins
-flips = ((m32 > 0) != (m16 > 0))
-dscore = torch.cat([(fl - bl).abs(), (fr - br).abs()])
 edges = [0.0, 1e-5, 3e-5, 1e-4, 3e-4, 1e-3, 3e-3, 1e-2, 1.0]
-hist_all = [int(((m32.abs() >= lo) & (m32.abs() < hi)).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
-hist_flip = [int(((m32.abs() >= lo) & (m32.abs() < hi) & flips).sum()) for lo, hi in zip(edges[:-1], edges[1:])]
-print(json.dumps({
-    "probe": "2AFC decisions, bf16 kernels vs fp32 kernel mode, SD1.5 512 px latents-in, up_blocks[0] step 600 cosine, synthetic weights",
-    "triplets": N, "decision_flips": int(flips.sum()), "flip_rate": float(flips.float().mean()),
-    "largest_fp32_margin_among_flips": float(m32[flips].abs().max()) if flips.any() else 0.0,
-    "margin_abs_edges": edges, "triplets_per_margin_bin": hist_all, "flips_per_margin_bin": hist_flip,
-    "score_abs_diff_max": float(dscore.max()), "score_abs_diff_mean": float(dscore.mean()),
-    "margin_abs_diff_max": float((m32 - m16).abs().max()), "margin_abs_diff_mean": float((m32 - m16).abs().mean()),
-    "fp32_margin_abs_median": float(m32.abs().median()), "score_range_fp32": [float(torch.cat([fl, fr]).min()), float(torch.cat([fl, fr]).max())],
-    "seconds": {"fp32": round(tf, 1), "bf16": round(tb, 1)}}))
+m32 = fl - fr                                         # decision margins of the fp32 kernel mode
+res = {"probe": "2AFC decisions, bf16 and fp16 kernels vs fp32 kernel mode, SD1.5 512 px latents-in, up_blocks[0] step 600 cosine, synthetic weights",
+       "triplets": N, "margin_abs_edges": edges,
+       "triplets_per_margin_bin": [int(((m32.abs() >= lo) & (m32.abs() < hi)).sum()) for lo, hi in zip(edges[:-1], edges[1:])],
+       "fp32_margin_abs_median": float(m32.abs().median()), "fp32_seconds": round(tf, 1), "fp32_scores_sample": fl[:4].tolist()}
+for name in ("bf16", "fp16"):
+    bl, br, tb = out[name]
+    m16 = bl - br
+    flips = ((m32 > 0) != (m16 > 0))
+    dscore = torch.cat([(fl - bl).abs(), (fr - br).abs()])
+    res[name] = {"decision_flips": int(flips.sum()), "flip_rate": float(flips.float().mean()),
+                 "largest_fp32_margin_among_flips": float(m32[flips].abs().max()) if flips.any() else 0.0,
+                 "flips_per_margin_bin": [int(((m32.abs() >= lo) & (m32.abs() < hi) & flips).sum()) for lo, hi in zip(edges[:-1], edges[1:])],
+                 "score_abs_diff_max": float(dscore.max()), "score_abs_diff_mean": float(dscore.mean()), "seconds": round(tb, 1)}
+print(json.dumps(res))

@@ -103,13 +103,18 @@ def newest_pmc_file(model: str, suffix: str, kernel: str = None):
     return None
 
 
+PMC_SOURCES = {}            # suffix -> basename of the summary the fields of this line were read from
+
+
 def _newest_pmc(suffix: str, kernel: str, field: str):
     """`field` of `kernel` from the newest committed rocprofv3 PMC summary of THIS model's pass (separate --pmc passes of
     this same command, gfx950 FETCH_SIZE x2 correction applied: profiles/summarize.py).  PMC counters cannot be read
-    from inside a normal run, so this is the committed measurement, or None."""
+    from inside a normal run, so this is the committed measurement, or None; the file it came from is named in the
+    line's `pmc_source` (profiles/collect_round.sh re-points a snapshot's lines at the snapshot's own passes)."""
     f = newest_pmc_file(PMC_MODEL, suffix, kernel)
     if f is None:
         return None
+    PMC_SOURCES[suffix] = os.path.basename(f)
     return json.load(open(f))[kernel][field]
 
 
@@ -206,6 +211,7 @@ def roofline_fields(recs, peak, tail=None, dump=None):
         order.insert(0, first)
     dom = entry(order[0])
     dom["traffic"] = pmc_traffic(dom["kernel"])
+    dom["pmc_source"] = {"traffic": PMC_SOURCES.get("pmc_hbm"), "mfma_util_pmc": PMC_SOURCES.get("pmc_mfma")}
     out = {"roofline": dom, "roofline_top_kernels": [entry(n_) for n_ in order[1:7]],
            "kernel_breakdown_ms_per_step": {
                k_: {"n": v_[0], "ms": round(v_[3], 3),

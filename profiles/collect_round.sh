@@ -14,5 +14,25 @@ python3 profiles/launch_table.py $T $G/launches_${T}.jsonl 40
 for f in "" _10k _two_streams _sdxl _dit _dit_fp8 _pixels_in _unfused _dedup_cfg _files_in; do
   [ -s $G/bench_${T}$f.json ] && tail -n 1 $G/bench_${T}$f.json | python3 -c "import json,sys; json.dump(json.loads(sys.stdin.read()), open('profiles/${T}_bench$f.json','w'), indent=1)"
 done
+# the lines were printed before this snapshot's PMC passes were summarised: point their PMC fields at the snapshot's own files
+python3 - $T <<'PY'
+import json, os, sys
+tag = sys.argv[1]
+for suffix, model in (("", ""), ("_10k", ""), ("_two_streams", ""), ("_unfused", ""), ("_dedup_cfg", ""), ("_sdxl", "sdxl_"), ("_dit", "dit_"), ("_dit_fp8", "dit_")):
+    p = f"profiles/{tag}_bench{suffix}.json"
+    hb, mf = f"profiles/{tag}_{model}pmc_hbm.json", f"profiles/{tag}_{model}pmc_mfma.json"
+    if not (os.path.exists(p) and os.path.exists(hb) and os.path.exists(mf)):
+        continue
+    d, H, M = json.load(open(p)), json.load(open(hb)), json.load(open(mf))
+    for e in [d.get("roofline", {})] + d.get("roofline_top_kernels", []):
+        k = e.get("kernel")
+        if k in M and "mfma_util_pmc" in e:
+            e["mfma_util_pmc"] = M[k]["mfma_util"]
+    r = d.get("roofline", {})
+    if r.get("kernel") in H:
+        r["traffic"] = H[r["kernel"]]["hbm_bytes_per_launch"]
+        r["pmc_source"] = {"traffic": os.path.basename(hb), "mfma_util_pmc": os.path.basename(mf)}
+    json.dump(d, open(p, "w"), indent=1)
+PY
 cp $G/batch_sweep_${T}.txt profiles/${T}_batch_sweep.txt
 ls profiles/${T}_*

@@ -175,14 +175,18 @@ def test_bench_pmc_fields_come_from_the_pass_of_the_same_model():
             for kernel in d:
                 f2 = bench.newest_pmc_file(model, suffix, kernel)
                 assert fn(kernel) == json.load(open(f2))[kernel][field]
-    # the headline line of the newest committed snapshot: its traffic is the SD1.5 pass's number for the roofline kernel
+    # the headline line of the newest committed snapshot: its traffic is the number of the SD1.5 pass it names as its source, and that
+    # source is an SD1.5 file (never the SDXL / DiT pass that lists the same kernel symbol)
     bench.PMC_MODEL = "sd15"
-    f = bench.newest_pmc_file("sd15", "pmc_hbm")
-    tag = os.path.basename(f).split("_")[0]
+    f = newest = bench.newest_pmc_file("sd15", "pmc_hbm")
+    tag = os.path.basename(newest).split("_")[0]
     bl = os.path.join(root, "profiles", f"{tag}_bench.json")
     if os.path.exists(bl) and int(re.match(r"r(\d+)", tag).group(1)) >= 4:      # lines before round 4 carry the old lookup
         line = json.load(open(bl))
-        assert line["roofline"]["traffic"] == json.load(open(f))[line["roofline"]["kernel"]]["hbm_bytes_per_launch"]
+        src = line["roofline"]["pmc_source"]["traffic"]
+        assert bench.pmc_file_class("sd15", "pmc_hbm").match(src), src
+        assert line["roofline"]["traffic"] == json.load(open(os.path.join(root, "profiles", src)))[line["roofline"]["kernel"]]["hbm_bytes_per_launch"]
+        assert src == os.path.basename(f)                 # collect_round.sh points a snapshot's line at the snapshot's own passes
 
 
 def test_public_header_is_plain_c99(tmp_path):

@@ -233,6 +233,9 @@ bool gemm_skinny_applies(const GemmArgs& a) {
     if (a.epi == EPI_GEGLU || a.act != 0 || a.gate != nullptr || a.out_split) return false;
     if (a.K < 8 * 64 || a.K % 64 || a.C0 % 64 || (a.A1 && a.C1 % 64) || a.N % 8) return false;
     const long reg_tiles = (long)((a.M + 127) / 128) * ((a.N + 159) / 160);
+#ifdef DSIM_DEVTOOLS
+    if (g_gemm_skinny == 2) return reg_tiles <= 2 * cu_count();          // kbench: widen the rule for a sweep
+#endif
     return reg_tiles * 4 <= cu_count();
 }
 

@@ -100,6 +100,7 @@ static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H,
         if (v == 0 && getenv("KB_NOPERSIST")) { g_force_bm = 0; g_gemm_persistent = 0; }   // column 1 = auto tiles, one tile per workgroup
         msv[v] = t.run([&] { st = launch_gemm(g, DSIM_BF16, 0); }, iters);
     }
+    if (getenv("KB_SKINNY") && atoi(getenv("KB_SKINNY")) == 2) g_gemm_skinny = 2;      // widened applies() rule for the sweep
     if (getenv("KB_SKINNY") && gemm_skinny_applies(g)) {      // small-batch kernel: gemm_kernel against every skinny tile (interleaved rounds)
         const int tiles[5] = {-1, (64 << 8) | 64, (128 << 8) | 64, (64 << 8) | 128, (128 << 8) | 128};
         const int rounds = getenv("KB_ROUNDS") ? atoi(getenv("KB_ROUNDS")) : 5;
@@ -107,7 +108,7 @@ static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H,
         g_force_bm = 0;
         for (int r = 0; r < rounds; ++r)
             for (int k = 0; k < 5; ++k) {
-                g_gemm_skinny = tiles[k] >= 0; g_skinny_tile = tiles[k] > 0 ? tiles[k] : 0;
+                g_gemm_skinny = tiles[k] >= 0 ? (atoi(getenv("KB_SKINNY")) == 2 ? 2 : 1) : 0; g_skinny_tile = tiles[k] > 0 ? tiles[k] : 0;
                 ms[k].push_back(t.run([&] { st = launch_gemm(g, DSIM_BF16, 0); }, iters));
             }
         g_gemm_skinny = 1; g_skinny_tile = 0;

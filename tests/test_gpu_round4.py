@@ -272,3 +272,56 @@ def test_tapped_qkv_as_one_launch_is_bit_identical():
         qs, ks, vs = eng.qkv(lat.cuda(), nz.cuda(), sa, sb, ctx.cuda(), out=sep)
         assert torch.equal(qs, q1) and torch.equal(ks, k1) and torch.equal(vs, v1), dtype
         del one, three
+
+
+def test_fp16_mode_of_the_sdxl_and_dit_scorers(golden_dir):
+    """diffsim_xl / diffsim_DiT in fp16 (the dtype the reference constructs them in, diffsim_xl.py / diffsim_dit.py) against the
+    goldens the reference's own code produced and the oracle: closer than the bf16 mode on average; the e4m3 attention option of
+    the DiT scorer stays a bf16-mode feature and says so."""
+    import ast
+    import os
+    import numpy as np
+    from oracle import cpu_ref as R
+    from diffsim_amd import _lib
+    from diffsim_amd.diffsim_xl import diffsim_xl
+    from diffsim_amd.diffsim_dit import diffsim_DiT
+    # ---- SDXL topology
+    sd = S.make_state_dict(C.SDXL_TINY, seed=0)
+    ctx, pooled = S.make_context(C.SDXL_TINY), S.make_pooled(C.SDXL_TINY)
+    g = np.load(os.path.join(golden_dir, "g8_sdxl_tiny.npz"))
+    zA, zB, nA, nB = (torch.from_numpy(g[k]) for k in ("latA", "latB", "noiseA", "noiseB"))
+    x16 = diffsim_xl(torch.float16, "cuda", unet_config=C.SDXL_TINY, state_dict=sd)
+    xbf = diffsim_xl(torch.bfloat16, "cuda", unet_config=C.SDXL_TINY, state_dict=sd)
+    assert x16.dtype == torch.float16
+    e16 = ebf = 0.0
+    for ci in range(6):
+        blk, tl, step, sim = (str(x) for x in g[f"case_{ci}"])
+        tl, step = ast.literal_eval(tl), int(step)
+        want = float(g[f"score_{ci}"][0])
+        s16 = float(x16.score_latent_pairs(zA, zB, nA, nB, ctx, pooled, blk, tl, step, sim).cpu())
+        sbf = float(xbf.score_latent_pairs(zA, zB, nA, nB, ctx, pooled, blk, tl, step, sim).cpu())
+        assert abs(s16 - want) <= 4e-3 * max(abs(want), 1.0), (ci, s16, want)
+        e16 += abs(s16 - want); ebf += abs(sbf - want)
+    assert e16 < ebf, (e16, ebf)
+    # ---- DiT
+    sdd = S.make_state_dict(C.DIT_TINY, seed=0)
+    m = R.DiTOracle(R.DIT_TINY)
+    m.load_state_dict(sdd, strict=True)
+    m.eval()
+    gd = np.load(os.path.join(golden_dir, "g9_dit_tiny.npz"))
+    zA, zB, nA, nB = (torch.from_numpy(gd[k]) for k in ("latA", "latB", "noiseA", "noiseB"))
+    d16 = diffsim_DiT(128, 600, "cuda", dit_config=C.DIT_TINY, state_dict=sdd, torch_dtype=torch.float16)
+    dbf = diffsim_DiT(128, 600, "cuda", dit_config=C.DIT_TINY, state_dict=sdd, torch_dtype=torch.bfloat16)
+    e16 = ebf = 0.0
+    for ci in range(4):
+        layer, step, sim = (str(x) for x in gd[f"case_{ci}"])
+        layer, step = int(layer), int(step)
+        so = float(R.diffsim_dit_latents(m, zA, zB, nA, nB, step, layer, sim))
+        s16 = float(d16.score_latent_pairs(zA, zB, nA, nB, layer, step, sim).cpu())
+        sbf = float(dbf.score_latent_pairs(zA, zB, nA, nB, layer, step, sim).cpu())
+        assert abs(s16 - so) <= 4e-3 * max(abs(so), 1.0), (ci, s16, so)
+        e16 += abs(s16 - so); ebf += abs(sbf - so)
+    assert e16 < ebf, (e16, ebf)
+    with pytest.raises((_lib.DsimError, ValueError)):
+        d8 = diffsim_DiT(128, 600, "cuda", dit_config=C.DIT_TINY, state_dict=sdd, torch_dtype=torch.float16, fp8_attention=True)
+        d8.score_latent_pairs(zA, zB, nA, nB, 2, 600, "cosine")

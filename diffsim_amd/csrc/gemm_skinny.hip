@@ -22,7 +22,6 @@ constexpr int SNW = 4, SBK_BYTES = 128;
 // SBM x SBN tile (multiples of 32), 4 waves as 2 x 2; ring of SDEPTH slots (as many as fit in 144 KB, at most 8)
 template <int MODE, bool RES, int SBM, int SBN>
 __global__ __launch_bounds__(SNW * 64, 1) void gemm_skinny_kernel(const GemmArgs p, const int tilesN) {
-    typedef h16 T;
     constexpr int BK = 64, ES = 2;
     constexpr int SSTAGE = (SBM + SBN) * SBK_BYTES;
     constexpr int SDEPTH = (144 * 1024 / SSTAGE) < 8 ? (144 * 1024 / SSTAGE) : 8;      // SDEPTH - 1 K tiles in flight

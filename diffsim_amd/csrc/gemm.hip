@@ -247,6 +247,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                 a_voff[i] = a_base[i] != OOB ? a_base[i] * (unsigned)p.C1 * (unsigned)sizeof(T) + celb : OOB;
         }
     };
+    // (DMAW: the LDS destination of a DMA piece is wave-uniform -- formed from the scalar wave index, M0 is then one s_add per piece
+    //  instead of v_add + v_readfirstlane + s_mov: 1-2 % on the convs, profiles/r04_experiments.txt item 7)
+#define DMAW wave_u
     auto issue = [&](int t, int buf) {
         char* sa = smem + (buf ? STAGE + SPARE : 0);
         char* sb = sa + A_BYTES;
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
         }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            auto lds = (__attribute__((address_space(3))) void*)(sa + (i * NW + wave) * 1024);
+            auto lds = (__attribute__((address_space(3))) void*)(sa + (i * NW + DMAW) * 1024);
             if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, lds, 16, (int)a_voff[i], soff, 0, 0);
             else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, lds, 16, (int)a_voff[i], soff, 0, 0);
         }
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
 #pragma unroll
         for (int i = 0; i < NB; ++i)
             if (i + 1 < NB || b_tail)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(sb + (i * NW + wave) * 1024),
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(sb + (i * NW + DMAW) * 1024),
                                                          16, (int)b_voff[i], soffw, 0, 0);
     };
     auto stage = [&](int t, int buf) { derive(t); issue(t, buf); };

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(SNW * 64, 1) void gemm_skinny_kernel(const GemmArgs
     static_assert(SDEPTH >= 3 && (SDEPTH - 2) * SPW <= 63, "ring");
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar: the DMA pieces' LDS destinations need no v_readfirstlane)
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, quad = lane >> 4, lrow = lane >> 3;
     const int wrow = wave * 8 + lrow;                                 // row inside a 32-row group of DMA pieces

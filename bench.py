@@ -48,7 +48,7 @@ def rocprof_name(fam: str) -> str:
     if p[0] == "gemm":
         t = {"bf16": "__bf16", "f16": "_Float16"}.get(p[1], "float")
         bm, bn = p[2].split("x")
-        mode = "1" if p[3] == "conv3" else "0"
+        mode = {"conv3": "1", "conv3p": "2"}.get(p[3], "0")      # conv3p: the instantiation for power-of-two output maps
         geglu = "true" if fam.endswith("_geglu") else "false"
         wn = "2" if bm == "256" else "1"          # 256-row tiles run 8 waves as 4x2, 128-row tiles 4x1
         # epilogue kind: plain / residual / DiT gate(+act, +residual) / DiT tanh-GELU only

@@ -107,7 +107,7 @@ static inline size_t dtype_size(int dt) { return dt == DSIM_F32 ? 4 : 2; }
 //   CONV3  : k = tap*C0 + c ; A(m,k) = X[b][iy][ix][c], zero outside, optional stride 2 /
 //            nearest-2x upsample folded into the index
 // ---------------------------------------------------------------------------------------------
-enum GemmMode { GEMM_LINEAR = 0, GEMM_CONV3 = 1 };
+enum GemmMode { GEMM_LINEAR = 0, GEMM_CONV3 = 1, GEMM_CONV3P = 2 };   // CONV3P: gemm_kernel's instantiation for power-of-two output maps (never in GemmArgs.mode)
 enum GemmEpi { EPI_NONE = 0, EPI_RESIDUAL = 1, EPI_GEGLU = 2 };
 
 struct GemmArgs {
@@ -118,6 +118,7 @@ struct GemmArgs {
     int Hin = 0, Win = 0, Hout = 0, Wout = 0;   // CONV3 geometry (Hin/Win = stored input size)
     int stride = 1, ups = 0;
     int pad = 1;                                // 1: symmetric padding; 0: VAE downsample (pad right/bottom only)
+    int lwo = -1, lhw = -1;                     // filled by launch_gemm: log2(Wout), log2(Hout * Wout) when both are powers of two, else -1
     int M = 0, N = 0, K = 0;                    // N counts packed weight rows (2x out cols for GEGLU)
     const void* W = nullptr;                    // packed [N][K], compute dtype
     const float* bias = nullptr;                // [N] f32 (packed order) or null

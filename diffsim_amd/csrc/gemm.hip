@@ -147,6 +147,8 @@ template <typename T, int BM, int BN, int MODE, bool GEGLU, int WM, int WN, int 
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p, const int tilesN, const int ntiles, const int tilesM,
                                                                const int gn) {
     constexpr int NW = WM * WN;
+    constexpr bool CONV = MODE != GEMM_LINEAR;             // GEMM_CONV3 or GEMM_CONV3P (output map sides are powers of two)
+    constexpr bool P2 = MODE == GEMM_CONV3P;
     constexpr int BK = Traits<T>::BK;
     constexpr int VEC = Traits<T>::VEC;
     constexpr int TM = BM / (WM * 16), TN = BN / (WN * 16);        // 16 x 16 accumulator tiles per wave
@@ -200,10 +202,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int m = m0 + i * (NW * 8) + wrow;
-            if (MODE == GEMM_CONV3) {
-                const int hw = p.Hout * p.Wout;
-                const int b = m / hw, rem = m - b * hw;
-                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            if (CONV) {
+                // output pixel -> (image, row, column): shifts when the output map's sides are powers of two (every SD level at
+                // the sizes the 256-row tiles serve), else two integer divisions per row -- setup() runs twice per tile, outside
+                // the MFMA shadow, and the divisions were ~440 of its VALU instructions per wave
+                int b, oy, ox;
+                if constexpr (P2) {
+                    b = m >> p.lhw;
+                    const int rem = m & ((1 << p.lhw) - 1);
+                    oy = rem >> p.lwo; ox = rem & ((1 << p.lwo) - 1);
+                } else {
+                    const int hw = p.Hout * p.Wout;
+                    b = m / hw;
+                    const int rem = m - b * hw;
+                    oy = rem / p.Wout; ox = rem - oy * p.Wout;
+                }
                 a_iy0[i] = (m < p.M) ? oy * p.stride - p.pad : -(1 << 20);
                 a_ix0[i] = ox * p.stride - p.pad;
                 a_base[i] = (unsigned)b * (unsigned)(p.Hin * p.Win);
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     // boundary, issue() launches the LDS-DMA pieces of this wave into staging buffer `buf`
     auto derive = [&](int t) {
         const int k0 = t * BK;
-        if (MODE == GEMM_CONV3) {
+        if (CONV) {
             const int tap = k0 / p.C0;
             if (k0 == tap * p.C0) {   // first K tile of a tap: re-derive the gathered pixel of every row
                 const int ky = tap / 3, kx = tap - ky * 3;
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
         const int k0 = t * BK;
         int soff;
         bool second = false;
-        if (MODE == GEMM_CONV3) {
+        if (CONV) {
             const int tap = k0 / p.C0;
             soff = (k0 - tap * p.C0) * (int)sizeof(T);
         } else {
@@ -324,7 +337,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     constexpr bool ACT = EK == EK_ACT;
     // linear layers start their accumulators at the bias (see the tile loop); the 3x3 conv keeps the bias add in its epilogue
     // (its K loop is long enough that the epilogue's loads do not matter, and the changed register allocation cost it 2.5 %)
-    constexpr bool BIAS_INIT = MODE == GEMM_LINEAR;
+    constexpr bool BIAS_INIT = !CONV;
     const bool has_res = EK == EK_RES || (SLOW && p.epi == EPI_RESIDUAL);
 
     int vb = blockIdx.x;
@@ -491,9 +504,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                 const int col = (GEGLU ? ((j >> 2) * 2 + (j & 1)) : j) * 16 + 4 * equad;
                 char* dst = wst + el15 * RSO + col * ES;
                 if constexpr (sizeof(T) == 2) {
-                    h16x4 pk;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = (h16)v[e];
+                    // two packed conversions (element-wise casts compiled to three v_cvt_pk + v_perm + v_alignbit per four values)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const h16x2 lo = __builtin_convertvector((f32x2){v[0], v[1]}, h16x2), hi = __builtin_convertvector((f32x2){v[2], v[3]}, h16x2);
+                    const h16x4 pk = {lo[0], lo[1], hi[0], hi[1]};
                     *reinterpret_cast<h16x4*>(dst) = pk;
                 } else {
                     f32x4 pk = {v[0], v[1], v[2], v[3]};
@@ -552,8 +566,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                     for (int e = 0; e < VEC; ++e) v[e] += (float)r[e];
                 }
                 V16 o16;
+                if constexpr (sizeof(T) == 2) {             // packed conversions, two values per instruction
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) o16[e] = (T)v[e];
+                    for (int e = 0; e < VEC; e += 2) {
+                        const h16x2 pr = __builtin_convertvector((f32x2){v[e], v[e + 1]}, h16x2);
+                        o16[e] = pr[0]; o16[e + 1] = pr[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) o16[e] = (T)v[e];
+                }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o16), rO, (int)off, 0, 0);
             }
         }
@@ -680,9 +703,19 @@ int check_args(const GemmArgs& a, int BK) {
 }
 
 template <typename T>
-int launch_typed(const GemmArgs& a, hipStream_t s) {
-    const int st = check_args(a, Traits<T>::BK);
+int launch_typed(const GemmArgs& a_in, hipStream_t s) {
+    const int st = check_args(a_in, Traits<T>::BK);
     if (st != DSIM_OK) return st;
+    GemmArgs a = a_in;
+    a.lwo = a.lhw = -1;
+    if (a.mode == GEMM_CONV3) {          // power-of-two output maps: the kernels split the pixel index with shifts
+        const int hw = a.Hout * a.Wout;
+        if (a.Wout > 0 && !(a.Wout & (a.Wout - 1)) && !(hw & (hw - 1))) {
+            a.lwo = a.lhw = 0;
+            while ((1 << a.lwo) < a.Wout) ++a.lwo;
+            while ((1 << a.lhw) < hw) ++a.lhw;
+        }
+    }
     if constexpr (sizeof(T) == 2) {
         // problems too small to fill the chip: 64 x 64 tiles behind a deep LDS ring, the same arithmetic bit for bit (gemm_skinny.hip)
         if (g_gemm_skinny && gemm_skinny_applies(a)) {
@@ -704,6 +737,10 @@ int launch_typed(const GemmArgs& a, hipStream_t s) {
             if (a.epi == EPI_GEGLU) return launch_one<T, 256, 256, GEMM_LINEAR, true, 4, 2>(a, s);
             if (a.mode == GEMM_CONV3) {
                 if (bn == 128) return launch_one<T, 256, 128, GEMM_CONV3, false, 4, 2>(a, s);
+                // power-of-two output maps (every SD level at the sizes these tiles serve): the instantiation without the integer
+                // divisions in setup(); a run-time branch instead spilled scalar registers in the residual kernel
+                if (a.lwo >= 0) return bn == 320 ? launch_one<T, 256, 320, GEMM_CONV3P, false, 4, 2>(a, s)
+                                                 : launch_one<T, 256, 256, GEMM_CONV3P, false, 4, 2>(a, s);
                 return bn == 320 ? launch_one<T, 256, 320, GEMM_CONV3, false, 4, 2>(a, s)
                                  : launch_one<T, 256, 256, GEMM_CONV3, false, 4, 2>(a, s);
             }

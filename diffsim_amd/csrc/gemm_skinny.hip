@@ -49,9 +49,17 @@ __global__ __launch_bounds__(SNW * 64, 1) void gemm_skinny_kernel(const GemmArgs
     for (int i = 0; i < NAP; ++i) {
         const int m = m0 + i * 32 + wrow;
         if (MODE == GEMM_CONV3) {
-            const int hw = p.Hout * p.Wout;
-            const int b = m / hw, rem = m - b * hw;
-            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            int b, oy, ox;
+            if (p.lwo >= 0) {
+                b = m >> p.lhw;
+                const int rem = m & ((1 << p.lhw) - 1);
+                oy = rem >> p.lwo; ox = rem & ((1 << p.lwo) - 1);
+            } else {
+                const int hw = p.Hout * p.Wout;
+                b = m / hw;
+                const int rem = m - b * hw;
+                oy = rem / p.Wout; ox = rem - oy * p.Wout;
+            }
             a_iy0[i] = (m < p.M) ? oy * p.stride - p.pad : -(1 << 20);
             a_ix0[i] = ox * p.stride - p.pad;
             a_base[i] = (unsigned)b * (unsigned)(p.Hin * p.Win);

@@ -82,9 +82,13 @@ struct Walk {
             int bm, bn;
             gemm_tile_choice(g, &bm, &bn);
             const bool skinny = h->dt != DSIM_F32 && gemm_skinny_applies(g);      // the small-batch kernel (gemm_skinny.hip)
+            // 256-row 16-bit conv tiles on power-of-two output maps run the CONV3P instantiation (gemm.hip launch_typed)
+            const int hwo = g.Hout * g.Wout;
+            const bool conv_p2 = g.mode == GEMM_CONV3 && !skinny && h->dt != DSIM_F32 && bm == 256 && bn != 128 && g.Wout > 0 &&
+                                 !(g.Wout & (g.Wout - 1)) && !(hwo & (hwo - 1));
             if (skinny) gemm_skinny_tile(g, &bm, &bn);
             const std::string nm = std::string(skinny ? "gemm_small_" : "gemm_") + dtn() + "_" + std::to_string(bm) + "x" + std::to_string(bn) +
-                                   (g.mode == GEMM_CONV3 ? "_conv3" : "_linear") +
+                                   (g.mode == GEMM_CONV3 ? (conv_p2 ? "_conv3p" : "_conv3") : "_linear") +
                                    (g.epi == EPI_GEGLU ? "_geglu" : (g.epi == EPI_RESIDUAL ? "_res" : ""));   // one family per kernel symbol
             const double e = (double)es();
             const double outc = g.epi == EPI_GEGLU ? g.N / 2 : g.N;

@@ -93,7 +93,7 @@ def test_sd15_full_size_fp16_pairs():
     s16.score_latent_pairs(zA, zB, n[2], n[3], ctx)
     fams = {r[0] for r in eng.profile_records()}
     eng.profile(False)
-    for f in ("ff_fused_f16", "ln_linear_f16", "attention_f16_d40_long", "gemm_f16_256x320_conv3"):
+    for f in ("ff_fused_f16", "ln_linear_f16", "attention_f16_d40_long", "gemm_f16_256x320_conv3p"):
         assert f in fams, (f, sorted(fams))
 
 

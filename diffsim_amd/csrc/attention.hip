@@ -1017,13 +1017,15 @@ template <typename T, int D>
 int launch_attn_d(const AttnArgs& a, hipStream_t s) {
     typedef ACfg<T, D> C;
     const dim3 grid(((a.Nq + 127) / 128) * a.H * a.B);
-    // long key sequences (the 64 x 64 self-attention: 64 key tiles per block): the fixed-reference softmax, 6 % faster at
-    // 4096 keys x d = 40; short ones (cross-attention's 77 keys, the 16 x 16 level) keep the exact running maximum -- there the
-    // end-of-block check costs more than the skipped maxima save
-    if constexpr (sizeof(T) == 2 && (D == 40 || D == 80)) {
+    // long key sequences (>= 1024 keys: the 64 x 64 and 32 x 32 self-attentions): the fixed-reference softmax -- 6 % faster at
+    // 4096 keys x d = 40, 10 % at 1024 keys x d = 80, 14 % at 1024 keys x d = 64 (SDXL); short ones (cross-attention's 77 keys,
+    // the 16 x 16 level: 0.179 -> 0.195 ms at 256 keys x d = 160) keep the exact running maximum -- there the end-of-block check
+    // costs more than the skipped maxima save
+    if constexpr (sizeof(T) == 2 && (D == 40 || D == 64 || D == 80)) {
         // the prompt context of the cross-attentions (77 keys): keys resident in LDS, several query blocks per workgroup
         // (interleaved A/B at 64 pairs: d = 40 0.502 -> 0.464 ms, d = 80 0.257 -> 0.227 ms; d = 160 at 256 queries: no gain, not used)
-        if (a.Nk <= 96 && g_attn_short) {
+        // (d = 64, SDXL, 32 pairs of rows: 1024 queries 0.055 -> 0.051 ms, 4096 queries 0.118 -> 0.123: the tiled kernel keeps those)
+        if (a.Nk <= 96 && g_attn_short && (D != 64 || a.Nq <= 1024)) {
             constexpr int LDSS = 96 * (C::RS + C::RSV);
             static DeviceOnce onces;
             auto kern = attn_short_kernel<D>;
@@ -1058,7 +1060,7 @@ int launch_attn_d(const AttnArgs& a, hipStream_t s) {
             return DSIM_OK;
         }
     }
-    if (sizeof(T) == 2 && a.Nk >= 2048) {
+    if (sizeof(T) == 2 && a.Nk >= g_attn_fast_min) {
         static DeviceOnce oncef;
         auto kern = attn_kernel<T, D, true>;
         CK_ONCE(oncef, kern, C::LDS);
@@ -1119,6 +1121,7 @@ int launch_tail_t(const void* q, const void* k, const void* v, const int32_t* ia
 int g_attn_q2 = 1;
 int g_attn_dbg = 0;
 int g_attn_short = 1;
+int g_attn_fast_min = 1024;
 #endif
 
 // Which kernel launch_attention picks for this problem, as the suffix of the profile family name (bench.py maps family names to
@@ -1127,9 +1130,9 @@ int g_attn_short = 1;
 // Mirrors launch_attn_d's conditions (the development switches are 1 in the product).
 const char* attention_kernel_kind(const AttnArgs& a, int dtype) {
     if (dtype == DSIM_F32) return "";
-    if ((a.D == 40 || a.D == 80) && a.Nk <= 96) return "_short";
+    if ((a.D == 40 || a.D == 80 || (a.D == 64 && a.Nq <= 1024)) && a.Nk <= 96) return "_short";
     if (a.D == 40 && a.Nk >= 2048 && a.Nk % KT == 0) return "_long";
-    if (a.Nk >= 2048) return "_fast";
+    if (a.Nk >= g_attn_fast_min) return "_fast";
     return "";
 }
 

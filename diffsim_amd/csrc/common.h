@@ -128,6 +128,7 @@ struct GemmArgs {
     const float* gate = nullptr;                // optional per-column scale applied before the residual add (DiT adaLN
     const float* gate2 = nullptr;               //   gates); gate2 = the ODD batch elements' vector
     int epi = EPI_NONE;
+    int geglu_blk = 32;                         // EPI_GEGLU: rows per alternating [h | g] block of the packed weight (geglu_block_rows())
     const void* residual = nullptr;             // [M][ldo]
     void* out = nullptr;
     int ldo = 0;
@@ -140,6 +141,10 @@ struct GemmArgs {
 #endif
 };
 int launch_gemm(const GemmArgs& a, int dtype, hipStream_t s);
+// Rows per alternating block of a GEGLU-interleaved weight with N packed rows (= 8C): 16 where the 320 / 160-column GEMM tiles
+// divide N (their waves hold 160 or 80 packed rows: five or ten 16-row accumulator tiles, an odd count of 32-row blocks); 32 for
+// the 320-channel blocks, whose weights the fused feed-forward streams (32 x 32 MFMAs), and for widths the 256 / 128-column tiles serve.
+inline int geglu_block_rows(int N) { return (N % 320 == 0 && N != 8 * 320) ? 16 : 32; }
 // Development switches (kernel A/B in tools/kbench, environment overrides): they exist only in -DDSIM_DEVTOOLS builds
 // (tools/build_kbench.py); the product library compiles them away as constants.
 #ifdef DSIM_DEVTOOLS
@@ -154,11 +159,12 @@ extern int g_prep8;             // DSIM_PREP8
 extern int g_attn_q2;           // 0 = long-key attention with one query block per wave (attn_kernel)
 extern int g_attn_dbg;          // ablation mask of attn_long_kernel
 extern int g_attn_short;        // 0 = short key sequences through attn_kernel
+extern int g_attn_fast_min;     // fewest keys that take the fixed-reference softmax of attn_kernel
 extern int g_ff_dbg;            // ablation mask of the fused feed-forward kernel (rowres.hip)
 extern int g_rl_dbg;            // ablation mask of the row-resident Linear kernel (rowres.hip)
 extern int g_ff_stagger;        // its wave de-phasing, in s_nop 7 units per wave index
 #else
-constexpr int g_gemm_skinny = 1, g_gemm_persistent = 1, g_force_bm = 0, g_gn_onepass = 1, g_ln_rows = 1, g_prep8 = 1, g_attn_q2 = 1, g_attn_short = 1;
+constexpr int g_gemm_skinny = 1, g_gemm_persistent = 1, g_force_bm = 0, g_gn_onepass = 1, g_ln_rows = 1, g_prep8 = 1, g_attn_q2 = 1, g_attn_short = 1, g_attn_fast_min = 1024;
 #endif
 int gemm_fill_extents(GemmArgs& g, size_t es);                       // operand byte extents for the buffer descriptors
 bool gemm_skinny_applies(const GemmArgs& a);                         // small-batch kernel (gemm_skinny.hip): same arithmetic, deep ring
@@ -169,7 +175,7 @@ void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn);   // which template 
 
 // weight repack kernels -- pack.hip  (src f32/h16/f16 diffusers layout -> packed compute dtype)
 int pack_linear(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int K,
-                int geglu_interleave, hipStream_t s);                       // [N][K] -> [N][K]
+                int geglu_interleave, hipStream_t s);                       // [N][K] -> [N][K]; geglu_interleave: 0 or the block rows (16 / 32)
 int pack_conv3(const void* src, int src_dtype, void* dst, int dst_dtype, int Cout, int Cin,
                hipStream_t s);                                              // [Co][Ci][3][3] -> [Co][9][Ci]
 int pack_conv_in(const void* src, int src_dtype, float* dst, int Cout, int Cin, hipStream_t s);   // -> f32 [9*Ci][Co]

@@ -37,7 +37,18 @@ int g_gemm_skinny = 1;
 // 256-row tiles to fill the chip: 256 x 320 (or 256 x 256, or 256 x 192 for the DiT widths) tiles, 8 waves as 4 x 2.
 void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn) {
     const bool geglu = a.epi == EPI_GEGLU;
+    if (geglu && a.geglu_blk == 16) {                      // 16-row [h | g] blocks: the 320 / 160-column tiles (N % 320 == 0)
+        const long tiles = (long)((a.M + 255) / 256) * (a.N / 320);
+        const bool big = g_force_bm ? g_force_bm == 256 : tiles >= 256;
+        *bm = big ? 256 : 128;
+        *bn = big ? 320 : 160;
+        return;
+    }
+#ifdef DSIM_DEVTOOLS
+    const bool n320 = !geglu && a.N % 320 == 0 && !(g_gemm_exp & 4096), n256 = a.N % 256 == 0;
+#else
     const bool n320 = !geglu && a.N % 320 == 0, n256 = a.N % 256 == 0;
+#endif
     // 192-wide: the DiT widths (1152, 3456) that neither 320 nor 256 divides; linear layers only
     bool n192 = !geglu && a.mode == GEMM_LINEAR && !n320 && !n256 && a.N % 192 == 0;
     // ... unless a ragged last 256-wide tile wastes at most 5 % of the columns (DiT's fused qkv, N = 3456: 13.5 tiles): the
@@ -155,7 +166,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     // weight fragments per piece of the K loop (a piece = PS x TM MFMAs between two pinned read groups)
     constexpr int PS = TM >= 4 ? 2 : (TN % 5 == 0 ? 5 : 4);
     constexpr int NP = TN / PS;                                    // pieces per 64-byte K step
-    static_assert(TN % PS == 0 && (GEGLU ? TN % 4 == 0 : true), "wave tile");
+    static_assert(TN % PS == 0 && (GEGLU ? TN % 2 == 0 : true), "wave tile");
+    // GEGLU weights alternate [h | g] blocks of 32 packed rows (accumulator tiles [h, h, g, g]: tile j pairs with j + 2) or, for the
+    // wave widths that are not a multiple of 64 columns (160, 80), of 16 rows (tiles [h, g]: j pairs with j + 1)
+    constexpr bool G16 = GEGLU && TN % 4 != 0;
     constexpr int WBN = BN / WN;                           // columns per wave
     constexpr int NA = BM / (NW * 8);                      // 8-row DMA pieces of A per wave per stage
     constexpr int NBP = BN / 8;                            // 8-row DMA pieces of B per stage (all waves)
@@ -476,12 +490,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 // GEGLU: packed weight rows alternate 32-row blocks [h-block, g-block] = tiles [h, h, g, g]: tile j (j & 2 == 0)
-                // pairs with tile j + 2, same lane, same register
-                if (GEGLU && (j & 2)) continue;
+                // pairs with tile j + 2, same lane, same register (16-row blocks: tiles [h, g], j pairs with j + 1)
+                if (GEGLU && (j & (G16 ? 1 : 2))) continue;
                 float v[4];
                 if (GEGLU) {
+                    constexpr int JG = G16 ? 1 : 2;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * (sizeof(T) == 2 ? gelu_fast(acc[i][j + 2][e]) : gelu_erf(acc[i][j + 2][e]));
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * (sizeof(T) == 2 ? gelu_fast(acc[i][j + JG][e]) : gelu_erf(acc[i][j + JG][e]));
                 } else if (BIAS_INIT) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
@@ -501,7 +516,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + b4[e];
                 }
-                const int col = (GEGLU ? ((j >> 2) * 2 + (j & 1)) : j) * 16 + 4 * equad;
+                const int col = (GEGLU ? (G16 ? (j >> 1) : ((j >> 2) * 2 + (j & 1))) : j) * 16 + 4 * equad;
                 char* dst = wst + el15 * RSO + col * ES;
                 if constexpr (sizeof(T) == 2) {
                     // two packed conversions (element-wise casts compiled to three v_cvt_pk + v_perm + v_alignbit per four values)
@@ -694,7 +709,8 @@ int check_args(const GemmArgs& a, int BK) {
     } else {
         if (a.C0 % BK || (a.A1 && a.C1 % BK) || a.K != a.C0 + (a.A1 ? a.C1 : 0)) return DSIM_ERR_INVALID;
     }
-    if (a.epi == EPI_GEGLU && (a.mode != GEMM_LINEAR || a.N % 64)) return DSIM_ERR_INVALID;
+    if (a.epi == EPI_GEGLU && (a.mode != GEMM_LINEAR || (a.geglu_blk == 16 ? a.N % 320 != 0 : (a.geglu_blk != 32 || a.N % 64))))
+        return DSIM_ERR_INVALID;
     if (!a.zero_page) return DSIM_ERR_INVALID;
     if (a.out_split && (a.mode != GEMM_LINEAR || a.epi != EPI_NONE || a.act || a.gate || a.out_split % 320 || a.N % a.out_split ||
                         a.out_split_stride <= 0 || (a.N / a.out_split) * a.out_split_stride >= 0x7fffffffll))
@@ -708,6 +724,9 @@ int launch_typed(const GemmArgs& a_in, hipStream_t s) {
     if (st != DSIM_OK) return st;
     GemmArgs a = a_in;
     a.lwo = a.lhw = -1;
+#ifdef DSIM_DEVTOOLS
+    if (a.epi == EPI_GEGLU && (g_gemm_exp & 8192) && a.N % 64 == 0) a.geglu_blk = 32;      // kbench: the 256 / 128-column GEGLU tiles
+#endif
     if (a.mode == GEMM_CONV3) {          // power-of-two output maps: the kernels split the pixel index with shifts
         const int hw = a.Hout * a.Wout;
         if (a.Wout > 0 && !(a.Wout & (a.Wout - 1)) && !(hw & (hw - 1))) {
@@ -729,12 +748,14 @@ int launch_typed(const GemmArgs& a_in, hipStream_t s) {
     const bool slow = a.act != 0 || a.gate != nullptr;     // DiT linears only
     if (slow && (a.mode != GEMM_LINEAR || a.epi == EPI_GEGLU)) return DSIM_ERR_INVALID;
     if (slow && bm == 256 && bn == 320) bm = 128;          // the SLOW instantiations are 256x256, 256x192 and 128x128
-    const bool big = bm == 256, n160 = bn == 160;
+    // (the f32 parity mode has 128-row tiles only; its GEGLU with 16-row blocks needs the 160-column one whatever the size)
+    const bool big = bm == 256, n160 = bn == 160 || (a.epi == EPI_GEGLU && a.geglu_blk == 16);
     (void)big;
     if constexpr (sizeof(T) == 2) {
         // h16, big problems: 256-row tiles, 8 waves as 4(M) x 2(N), 64-row x (BN/2)-column sub-tiles
         if (big) {
-            if (a.epi == EPI_GEGLU) return launch_one<T, 256, 256, GEMM_LINEAR, true, 4, 2>(a, s);
+            if (a.epi == EPI_GEGLU)
+                return bn == 320 ? launch_one<T, 256, 320, GEMM_LINEAR, true, 4, 2>(a, s) : launch_one<T, 256, 256, GEMM_LINEAR, true, 4, 2>(a, s);
             if (a.mode == GEMM_CONV3) {
                 if (bn == 128) return launch_one<T, 256, 128, GEMM_CONV3, false, 4, 2>(a, s);
                 // power-of-two output maps (every SD level at the sizes these tiles serve): the instantiation without the integer
@@ -752,7 +773,7 @@ int launch_typed(const GemmArgs& a_in, hipStream_t s) {
         }
     }
     if (slow) return launch_one<T, 128, 128, GEMM_LINEAR, false, 4, 1, true>(a, s);
-    if (a.epi == EPI_GEGLU) return launch_one<T, 128, 128, GEMM_LINEAR, true>(a, s);
+    if (a.epi == EPI_GEGLU) return n160 ? launch_one<T, 128, 160, GEMM_LINEAR, true>(a, s) : launch_one<T, 128, 128, GEMM_LINEAR, true>(a, s);
     if (a.mode == GEMM_CONV3)
         return n160 ? launch_one<T, 128, 160, GEMM_CONV3, false>(a, s) : launch_one<T, 128, 128, GEMM_CONV3, false>(a, s);
     return n160 ? launch_one<T, 128, 160, GEMM_LINEAR, false>(a, s) : launch_one<T, 128, 128, GEMM_LINEAR, false>(a, s);

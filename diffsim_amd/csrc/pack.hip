@@ -21,10 +21,10 @@ __device__ __forceinline__ void st_any(void* p, int dt, size_t i, float v) {
 }
 
 // GEGLU row interleave: diffusers' ff.net.0.proj has rows [h (0..F) ; g (F..2F)].  The GEMM's
-// GEGLU epilogue wants packed rows in alternating 32-row blocks [h blk0, g blk0, h blk1, ...].
-__device__ __forceinline__ int geglu_src_row(int packed, int N) {
-    const int F = N >> 1, blk = packed >> 5, within = packed & 31;
-    const int j = (blk >> 1) * 32 + within;
+// GEGLU epilogue wants packed rows in alternating blocks of `rows` (32 or 16: geglu_block_rows()) [h blk0, g blk0, h blk1, ...].
+__device__ __forceinline__ int geglu_src_row(int packed, int N, int rows) {
+    const int F = N >> 1, blk = packed / rows, within = packed - blk * rows;
+    const int j = (blk >> 1) * rows + within;
     return (blk & 1) ? F + j : j;
 }
 
@@ -32,7 +32,7 @@ __global__ void pack_linear_kernel(const void* src, int sdt, void* dst, int ddt,
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)N * K) return;
     const int n = (int)(i / K), k = (int)(i - (size_t)n * K);
-    const int sn = geglu ? geglu_src_row(n, N) : n;
+    const int sn = geglu ? geglu_src_row(n, N, geglu) : n;
     st_any(dst, ddt, i, ld_any(src, sdt, (size_t)sn * K + k));
 }
 
@@ -59,7 +59,7 @@ __global__ void pack_conv_in_kernel(const void* src, int sdt, float* dst, int Co
 __global__ void pack_vector_kernel(const void* src, int sdt, float* dst, int N, int geglu) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    dst[i] = ld_any(src, sdt, geglu ? geglu_src_row(i, N) : i);
+    dst[i] = ld_any(src, sdt, geglu ? geglu_src_row(i, N, geglu) : i);
 }
 
 // one wave per output row
@@ -260,7 +260,7 @@ __global__ void convert_kernel(const float* src, void* dst, int ddt, size_t n) {
 }  // namespace
 
 int pack_linear(const void* src, int sdt, void* dst, int ddt, int N, int K, int geglu, hipStream_t s) {
-    if (geglu && (N % 64)) return DSIM_ERR_INVALID;
+    if (geglu && ((geglu != 16 && geglu != 32) || N % (2 * geglu))) return DSIM_ERR_INVALID;
     const size_t n = (size_t)N * K;
     hipLaunchKernelGGL(pack_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, sdt, dst, ddt, N, K, geglu);
     DSIM_HIP_CHECK(hipGetLastError());

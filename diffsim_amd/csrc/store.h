@@ -120,7 +120,7 @@ static inline int pack_all(WeightStore* h, hipStream_t s) {
             h->pk[key] = P;
         } else if (w.shape.size() == 1) {
             const int n = (int)w.shape[0];
-            const int geglu = ends_with(key, "ff.net.0.proj.bias");
+            const int geglu = ends_with(key, "ff.net.0.proj.bias") ? geglu_block_rows(n) : 0;
             CK(h->dalloc((size_t)n * 4, &P.p));
             P.rows = n; P.cols = 1; P.bytes = (size_t)n * 4;
             CK(pack_vector(w.p, w.dtype, (float*)P.p, n, geglu, s));
@@ -161,7 +161,7 @@ static inline int pack_all(WeightStore* h, hipStream_t s) {
                 CK(pack_linear(w.p, w.dtype, P.p, DSIM_F32, n, k, 0, s));
                 h->pk[key] = P;
             } else {
-                const int geglu = ends_with(key, "ff.net.0.proj.weight");
+                const int geglu = ends_with(key, "ff.net.0.proj.weight") ? geglu_block_rows(n) : 0;
                 CK(h->dalloc((size_t)n * k * es, &P.p));
                 P.rows = n; P.cols = k;
                 CK(pack_linear(w.p, w.dtype, P.p, dt, n, k, geglu, s));

@@ -109,6 +109,7 @@ struct Walk {
         g.M = M; g.N = N; g.K = c0 + (a1 ? c1 : 0);
         g.W = w->p; g.bias = b ? (const float*)b->p : nullptr;
         g.epi = epi >= 0 ? epi : (residual ? EPI_RESIDUAL : EPI_NONE);
+        if (g.epi == EPI_GEGLU) g.geglu_blk = geglu_block_rows(N);       // as pack_all() interleaved it
         g.residual = residual; g.out = out; g.ldo = ldo;
         return gemm(g);
     }
@@ -875,11 +876,13 @@ int dsim_op_linear(const void* x, const float* w, const float* bias, const void*
     void* zp = t.get(256);
     if (!wp || !zp || (bias && !bp)) return DSIM_ERR_HIP;
     DSIM_HIP_CHECK(hipMemsetAsync(zp, 0, 256, s));
-    CK(pack_linear(w, DSIM_F32, wp, dtype, NW, K, geglu, s));
-    if (bias) CK(pack_vector(bias, DSIM_F32, bp, NW, geglu, s));
+    const int gblk = geglu ? geglu_block_rows(NW) : 0;
+    CK(pack_linear(w, DSIM_F32, wp, dtype, NW, K, gblk, s));
+    if (bias) CK(pack_vector(bias, DSIM_F32, bp, NW, gblk, s));
     GemmArgs g;
     g.A0 = x; g.C0 = K; g.mode = GEMM_LINEAR; g.M = M; g.N = NW; g.K = K; g.W = wp; g.bias = bp;
     g.epi = geglu ? EPI_GEGLU : (residual ? EPI_RESIDUAL : EPI_NONE);
+    if (geglu) g.geglu_blk = gblk;
     g.residual = residual; g.out = out; g.ldo = N; g.zero_page = zp;
     CK(launch_gemm(g, dtype, s));
     DSIM_HIP_CHECK(hipStreamSynchronize(s));
@@ -937,8 +940,8 @@ int dsim_op_ff_fused(const void* x, const float* ln_gamma, const float* ln_beta,
     void* w2p = t.get((size_t)4 * C * C * 2);
     void* st = t.get(sb);
     if (!w1p || !b1p || !w2p || !st) return DSIM_ERR_HIP;
-    CK(pack_linear(w1, DSIM_F32, w1p, DSIM_BF16, 8 * C, C, 1, s));
-    CK(pack_vector(b1, DSIM_F32, b1p, 8 * C, 1, s));
+    CK(pack_linear(w1, DSIM_F32, w1p, DSIM_BF16, 8 * C, C, 32, s));
+    CK(pack_vector(b1, DSIM_F32, b1p, 8 * C, 32, s));
     CK(pack_linear(w2, DSIM_F32, w2p, DSIM_BF16, C, 4 * C, 0, s));
     CK(pack_ff_stream(w1p, w2p, st, C, s));
     FFArgs a;

@@ -90,6 +90,7 @@ static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H,
     g.A0 = A; g.C0 = Cin; g.A1 = A1; g.C1 = C1; g.mode = mode; g.Hin = g.Hout = H; g.Win = g.Wout = W; g.M = M; g.N = N; g.K = K;
     g.W = Wt; g.bias = bias; g.epi = epi; g.residual = epi == EPI_RESIDUAL ? res : nullptr; g.out = out; g.ldo = outc;
     g.zero_page = zp;
+    if (epi == EPI_GEGLU) g.geglu_blk = geglu_block_rows(N);      // KB_GEXP=8192: the 32-row blocks (256 / 128-column tiles) beside it
     int st = DSIM_OK;
     const double fl = 2.0 * M * (double)N * K;
     float msv[3];
@@ -200,6 +201,18 @@ static void bench_attn(const char* name, int B, int Bkv, int H, int Nq, int Nk, 
         }
         std::sort(q1.begin(), q1.end()); std::sort(q2.begin(), q2.end());
         printf("  tiled kernel %8.3f/%8.3f ms | short-key kernel %8.3f/%8.3f ms (min/median)\n", q1[0], q1[rounds / 2], q2[0], q2[rounds / 2]);
+    }
+    if (Nk >= 256 && Nk < 2048) {                 // exact running maximum against the fixed-reference softmax at mid-length key sequences
+        std::vector<float> q1, q2;
+        for (int r = 0; r < rounds; ++r) {
+            g_attn_fast_min = 2048;
+            q1.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
+            g_attn_fast_min = 256;
+            q2.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
+        }
+        g_attn_fast_min = 1024;
+        std::sort(q1.begin(), q1.end()); std::sort(q2.begin(), q2.end());
+        printf("  running maximum %8.3f/%8.3f ms | fixed reference %8.3f/%8.3f ms (min/median)\n", q1[0], q1[rounds / 2], q2[0], q2[rounds / 2]);
     }
     if (Nk >= 2048) {                             // one query block per wave (attn_kernel) against two (attn_long_kernel)
         std::vector<float> q1, q2;
@@ -427,6 +440,8 @@ int main(int argc, char** argv) {
     bench_gemm("lin_16_1280_1280_res", GEMM_LINEAR, s16, 1280, 1280, 0, 0, EPI_RESIDUAL, iters, t, zp);
     bench_gemm("lin_16_1280_3840_qkv", GEMM_LINEAR, s16, 3840, 1280, 0, 0, EPI_NONE, iters, t, zp);
     bench_gemm("lin_16_1280_10240_geglu", GEMM_LINEAR, s16, 10240, 1280, 0, 0, EPI_GEGLU, iters, t, zp);
+    bench_gemm("lin_16_1280_10240_plain", GEMM_LINEAR, s16, 10240, 1280, 0, 0, EPI_NONE, iters, t, zp);
+    bench_gemm("lin_32_640_5120_plain", GEMM_LINEAR, s32, 5120, 640, 0, 0, EPI_NONE, iters, t, zp);
     bench_gemm("lin_16_5120_1280_res", GEMM_LINEAR, s16, 1280, 5120, 0, 0, EPI_RESIDUAL, iters, t, zp);
     bench_gemm("lin_16_sc_2560_1280", GEMM_LINEAR, s16, 1280, 1280, 0, 0, EPI_NONE, iters, t, zp, 1280);
     bench_gemm("lin_kv_768_2560", GEMM_LINEAR, 154, 2560, 768, 0, 0, EPI_NONE, iters, t, zp);
@@ -437,6 +452,10 @@ int main(int argc, char** argv) {
     bench_attn("attn_cross_4096_d40", B2, 2, 8, 4096, 77, 40, iters, t);
     bench_attn("attn_cross_1024_d80", B2, 2, 8, 1024, 77, 80, iters, t);
     bench_attn("attn_cross_256_d160", B2, 2, 8, 256, 77, 160, iters, t);
+    bench_attn("attn_sdxl_self_4096_d64", B2, B2, 10, 4096, 4096, 64, iters, t);
+    bench_attn("attn_sdxl_self_1024_d64", B2, B2, 20, 1024, 1024, 64, iters, t);
+    bench_attn("attn_sdxl_cross_4096_d64", B2, 2, 10, 4096, 77, 64, iters, t);
+    bench_attn("attn_sdxl_cross_1024_d64", B2, 2, 20, 1024, 77, 64, iters, t);
     // ---- norms ----
     bench_gn("gn_64_320", B2, 4096, 320, iters, t);
     bench_gn("gn_16_1280", B2, 256, 1280, iters, t);

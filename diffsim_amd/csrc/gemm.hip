@@ -49,6 +49,25 @@ void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn) {
 #else
     const bool n320 = !geglu && a.N % 320 == 0, n256 = a.N % 256 == 0;
 #endif
+    // A ragged last 320-wide tile wasting <= 5 % of the columns (DiT: fused qkv N = 3456 = 10.8 tiles, Mlp.fc1 N = 4608 = 14.4) beats 256-wide tiles when the
+    // persistent grid's rounds come out shorter: the 64 x 160 wave tile is 5-10 % faster per column (profiles/r04_experiments.txt
+    // items 13, 15), a round is one tile per CU.  65536 x 3456 x 1152: 11 rounds of 320 against 14 of 256 (0.491 -> 0.467 ms);
+    // at 32768 rows 5.5 -> 6 rounds against 7: the 256-wide tiles stay (0.223 against 0.234 ms).
+    {
+        const int c320 = (a.N + 319) / 320, c256 = (a.N + 255) / 256, tm = (a.M + 255) / 256, cus = cu_count();
+#ifdef DSIM_DEVTOOLS
+        const bool allow = !(g_gemm_exp & 16384) && !(g_gemm_exp & 4096);
+#else
+        const bool allow = true;
+#endif
+        const bool act_only = a.act == 1 && !a.gate && a.epi != EPI_RESIDUAL;      // the epilogue kinds instantiated at 256 x 320
+        const long r320 = ((long)tm * c320 + cus - 1) / cus, r256 = ((long)tm * c256 + cus - 1) / cus;
+        if (allow && !geglu && a.mode == GEMM_LINEAR && !n320 && (act_only || (!a.act && !a.gate)) && (long)tm * c320 >= cus &&
+            (long)c320 * 320 * 20 <= (long)a.N * 21 && r320 * 320 * 19 <= r256 * 256 * 20 && g_force_bm != 128) {
+            *bm = 256; *bn = 320;
+            return;
+        }
+    }
     // 192-wide: the DiT widths (1152, 3456) that neither 320 nor 256 divides; linear layers only
     bool n192 = !geglu && a.mode == GEMM_LINEAR && !n320 && !n256 && a.N % 192 == 0;
     // ... unless a ragged last 256-wide tile wastes at most 5 % of the columns (DiT's fused qkv, N = 3456: 13.5 tiles): the
@@ -747,7 +766,8 @@ int launch_typed(const GemmArgs& a_in, hipStream_t s) {
     gemm_tile_choice(a, &bm, &bn);
     const bool slow = a.act != 0 || a.gate != nullptr;     // DiT linears only
     if (slow && (a.mode != GEMM_LINEAR || a.epi == EPI_GEGLU)) return DSIM_ERR_INVALID;
-    if (slow && bm == 256 && bn == 320) bm = 128;          // the SLOW instantiations are 256x256, 256x192 and 128x128
+    const bool act_only = a.act == 1 && !a.gate && a.epi != EPI_RESIDUAL;
+    if (slow && bm == 256 && bn == 320 && !act_only) bm = 128;          // the gated instantiations are 256x256, 256x192 and 128x128
     // (the f32 parity mode has 128-row tiles only; its GEGLU with 16-row blocks needs the 160-column one whatever the size)
     const bool big = bm == 256, n160 = bn == 160 || (a.epi == EPI_GEGLU && a.geglu_blk == 16);
     (void)big;
@@ -765,6 +785,7 @@ int launch_typed(const GemmArgs& a_in, hipStream_t s) {
                 return bn == 320 ? launch_one<T, 256, 320, GEMM_CONV3, false, 4, 2>(a, s)
                                  : launch_one<T, 256, 256, GEMM_CONV3, false, 4, 2>(a, s);
             }
+            if (slow && bn == 320) return launch_ek<T, 256, 320, GEMM_LINEAR, false, 4, 2, EK_ACT>(a, s);      // tanh-GELU only (DiT Mlp.fc1)
             if (slow) return bn == 192 ? launch_one<T, 256, 192, GEMM_LINEAR, false, 4, 2, true>(a, s)
                                        : launch_one<T, 256, 256, GEMM_LINEAR, false, 4, 2, true>(a, s);
             if (bn == 192) return launch_one<T, 256, 192, GEMM_LINEAR, false, 4, 2>(a, s);

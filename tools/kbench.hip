@@ -75,7 +75,7 @@ static const char* g_filter = nullptr;
 static bool want(const std::string& n) { return !g_filter || n.find(g_filter) != std::string::npos; }
 
 static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H, int W, int epi, int iters, Timer& t,
-                       void* zp, int C1 = 0) {
+                       void* zp, int C1 = 0, int act = 0, bool gated = false) {
     if (!want(name)) return;
     GemmArgs g;
     const int K = mode == GEMM_CONV3 ? 9 * Cin : Cin + C1;
@@ -90,6 +90,8 @@ static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H,
     g.A0 = A; g.C0 = Cin; g.A1 = A1; g.C1 = C1; g.mode = mode; g.Hin = g.Hout = H; g.Win = g.Wout = W; g.M = M; g.N = N; g.K = K;
     g.W = Wt; g.bias = bias; g.epi = epi; g.residual = epi == EPI_RESIDUAL ? res : nullptr; g.out = out; g.ldo = outc;
     g.zero_page = zp;
+    g.act = act;
+    if (gated) { g.gate = dalloc_f32(N, 7); g.rows_per_batch = 256; }
     if (epi == EPI_GEGLU) g.geglu_blk = geglu_block_rows(N);      // KB_GEXP=8192: the 32-row blocks (256 / 128-column tiles) beside it
     int st = DSIM_OK;
     const double fl = 2.0 * M * (double)N * K;
@@ -446,6 +448,11 @@ int main(int argc, char** argv) {
     bench_gemm("lin_16_sc_2560_1280", GEMM_LINEAR, s16, 1280, 1280, 0, 0, EPI_NONE, iters, t, zp, 1280);
     bench_gemm("lin_kv_768_2560", GEMM_LINEAR, 154, 2560, 768, 0, 0, EPI_NONE, iters, t, zp);
     // ---- attention ----
+    // DiT-XL/2 at 256 px: 256 tokens per image, hidden 1152 (B2 = 256 elements <-> 64 pairs, both CFG halves)
+    bench_gemm("lin_dit_qkv", GEMM_LINEAR, B2 * 256, 3456, 1152, 0, 0, EPI_NONE, iters, t, zp);
+    bench_gemm("lin_dit_fc1_act", GEMM_LINEAR, B2 * 256, 4608, 1152, 0, 0, EPI_NONE, iters, t, zp, 0, 1);
+    bench_gemm("lin_dit_proj_gate_res", GEMM_LINEAR, B2 * 256, 1152, 1152, 0, 0, EPI_RESIDUAL, iters, t, zp, 0, 0, true);
+    bench_gemm("lin_dit_fc2_gate_res", GEMM_LINEAR, B2 * 256, 1152, 4608, 0, 0, EPI_RESIDUAL, iters, t, zp, 0, 0, true);
     bench_attn("attn_self_4096_d40", B2, B2, 8, 4096, 4096, 40, iters, t);
     bench_attn("attn_self_1024_d80", B2, B2, 8, 1024, 1024, 80, iters, t);
     bench_attn("attn_self_256_d160", B2, B2, 8, 256, 256, 160, iters, t);

@@ -10,6 +10,7 @@
 #ifdef DSIM_H16_IS_F16
 #define launch_gemm launch_gemm_f16
 #define gemm_tile_choice gemm_tile_choice_f16
+#define gemm_launch_tile gemm_launch_tile_f16
 #define gemm_band_width gemm_band_width_f16
 #define gemm_fill_extents gemm_fill_extents_f16
 #define gemm_skinny_applies gemm_skinny_applies_f16
@@ -171,7 +172,8 @@ bool gemm_skinny_applies(const GemmArgs& a);                         // small-ba
 int launch_gemm_skinny(const GemmArgs& g /*extents filled*/, hipStream_t s);
 void gemm_skinny_tile(const GemmArgs& a, int* bm, int* bn);          // its tile for this problem
 int gemm_band_width(int tilesM, int tilesN, size_t w_tile_bytes);   // tile-order band width (L2 reuse of the weight tiles)
-void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn);   // which template instantiation launch_gemm picks
+void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn);   // the tile the problem's shape asks for
+void gemm_launch_tile(const GemmArgs& a, int dtype, int* bm, int* bn);   // ... and the instantiation launch_gemm picks for it (dtype: DSIM_F32 or a 16-bit one)
 
 // weight repack kernels -- pack.hip  (src f32/h16/f16 diffusers layout -> packed compute dtype)
 int pack_linear(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int K,

@@ -107,9 +107,8 @@ struct DWalk {
         if (!run) return DSIM_OK;
         if (h->profiling) {
             int bm, bn;
-            gemm_tile_choice(g, &bm, &bn);
+            gemm_launch_tile(g, h->dt, &bm, &bn);
             const bool slow = act != 0 || gate != nullptr;      // the tanh-GELU / adaLN-gate epilogue template (gemm.hip EK_SLOW)
-            if (slow && bm == 256 && bn == 320) bm = 128, bn = 128;
             pbegin(std::string("gemm_") + dtn() + "_" + std::to_string(bm) + "x" + std::to_string(bn) + "_linear" +
                        (slow ? ((act && !gate && !residual) ? "_act" : "_dit") : (residual ? "_res" : "")) + "|M" + std::to_string(M) + " N" + std::to_string(N) + " K" + std::to_string(K),
                    2.0 * M * (double)N * K, (double)es() * ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1)));

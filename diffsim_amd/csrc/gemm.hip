@@ -96,6 +96,22 @@ void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn) {
     *bn = (a.N % 160 == 0 && !geglu) ? 160 : 128;
 }
 
+// The tile gemm_kernel is launched with (gemm_tile_choice + what the instantiation set allows): the f32 parity mode has
+// 128-row tiles only (its GEGLU with 16-row blocks the 160-column one whatever the size); the gated DiT epilogues exist at
+// 256 x 256, 256 x 192 and 128 x 128, the tanh-GELU-only one also at 256 x 320.  The executors name their profile families by it.
+void gemm_launch_tile(const GemmArgs& a, int dtype, int* bm, int* bn) {
+    gemm_tile_choice(a, bm, bn);
+    const bool slow = a.act != 0 || a.gate != nullptr;
+    const bool act_only = a.act == 1 && !a.gate && a.epi != EPI_RESIDUAL;
+    bool big = *bm == 256 && dtype != DSIM_F32;
+    if (big && slow && *bn == 320 && !act_only) big = false;
+    if (!big) {
+        const bool n160 = *bn == 160 || (a.epi == EPI_GEGLU && a.geglu_blk == 16);
+        *bm = 128;
+        *bn = slow ? 128 : (n160 ? 160 : 128);
+    }
+}
+
 namespace {
 
 template <typename T> struct Traits;
@@ -762,14 +778,11 @@ int launch_typed(const GemmArgs& a_in, hipStream_t s) {
             return se != DSIM_OK ? se : launch_gemm_skinny(g, s);
         }
     }
-    int bm, bn;
-    gemm_tile_choice(a, &bm, &bn);
     const bool slow = a.act != 0 || a.gate != nullptr;     // DiT linears only
     if (slow && (a.mode != GEMM_LINEAR || a.epi == EPI_GEGLU)) return DSIM_ERR_INVALID;
-    const bool act_only = a.act == 1 && !a.gate && a.epi != EPI_RESIDUAL;
-    if (slow && bm == 256 && bn == 320 && !act_only) bm = 128;          // the gated instantiations are 256x256, 256x192 and 128x128
-    // (the f32 parity mode has 128-row tiles only; its GEGLU with 16-row blocks needs the 160-column one whatever the size)
-    const bool big = bm == 256, n160 = bn == 160 || (a.epi == EPI_GEGLU && a.geglu_blk == 16);
+    int bm, bn;
+    gemm_launch_tile(a, sizeof(T) == 2 ? DSIM_H16 : DSIM_F32, &bm, &bn);
+    const bool big = bm == 256, n160 = bn == 160;
     (void)big;
     if constexpr (sizeof(T) == 2) {
         // h16, big problems: 256-row tiles, 8 waves as 4(M) x 2(N), 64-row x (BN/2)-column sub-tiles

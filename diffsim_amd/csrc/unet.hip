@@ -80,7 +80,7 @@ struct Walk {
         if (!run) return DSIM_OK;
         if (h->profiling) {
             int bm, bn;
-            gemm_tile_choice(g, &bm, &bn);
+            gemm_launch_tile(g, h->dt, &bm, &bn);
             const bool skinny = h->dt != DSIM_F32 && gemm_skinny_applies(g);      // the small-batch kernel (gemm_skinny.hip)
             // 256-row 16-bit conv tiles on power-of-two output maps run the CONV3P instantiation (gemm.hip launch_typed)
             const int hwo = g.Hout * g.Wout;

@@ -166,7 +166,7 @@ static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H,
         printf("\n");
     }
     int bm, bn;
-    gemm_tile_choice(g, &bm, &bn);
+    gemm_launch_tile(g, DSIM_BF16, &bm, &bn);
     printf("%-26s M=%7d N=%5d K=%5d  bm128 %7.3f ms %6.1f TF | bm256 %7.3f ms %6.1f TF | auto %dx%d %7.3f ms %6.1f TF st=%d\n",
            name, M, N, K, msv[0], fl / msv[0] / 1e9, msv[1], fl / msv[1] / 1e9, bm, bn, msv[2], fl / msv[2] / 1e9, st);
     HC(hipFree(A)); if (A1) HC(hipFree(A1)); HC(hipFree(Wt)); HC(hipFree(bias)); HC(hipFree(res)); HC(hipFree(out));

@@ -222,21 +222,24 @@ int g_skinny_tile = 0;          // kbench: 0 heuristic, else (bm << 8) | bn
 
 // Tile of the small-batch kernel.  Per K tile a workgroup moves (bm + bn) x 128 B through its CU's L2 -> LDS path for
 // bm x bn x 64 MACs and one workgroup runs per CU (the ring fills LDS), so wider tiles move fewer bytes in total but leave CUs
-// idle.  Measured (tools/kbench KB_SKINNY=1, profiles/r04_small_batch.txt): 64 x 128 wins whenever it gives >= 0.6 workgroups
-// per CU (1024 x 1280: 0.103 ms against 0.146 for gemm_kernel and 0.148 for 64 x 64), 64 x 64 below that (256 x 1280:
-// 0.075 against 0.150); 128 x 64 is 5-10 % behind 64 x 128 and 128 x 128 never wins where this kernel applies.
+// idle.  Measured (tools/kbench KB_SKINNY=2, profiles/r04_small_batch.txt): the largest tile that still gives >= 0.6 workgroups
+// per CU wins -- 128 x 128 at 2048 x 1280 (160 workgroups: 0.132 ms against 0.188 for 64 x 128 and 0.146 for gemm_kernel),
+// 64 x 128 at 1024 x 1280 (0.103 against 0.146 / 0.148 for 64 x 64), 64 x 64 at 256 / 512 x 1280 (0.075 against 0.150); 128 x 64
+// is 5-10 % behind 64 x 128; more workgroups than CUs (a second round) always loses to gemm_kernel.
+static long skinny_count(const GemmArgs& a, int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); }
 void gemm_skinny_tile(const GemmArgs& a, int* bm, int* bn) {
 #ifdef DSIM_DEVTOOLS
     if (g_skinny_tile) { *bm = g_skinny_tile >> 8; *bn = g_skinny_tile & 255; return; }
 #endif
-    const long t128 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
+    const long fill = (long)cu_count() * 6;
+    if (skinny_count(a, 128, 128) * 10 >= fill) { *bm = 128; *bn = 128; return; }
     *bm = 64;
-    *bn = t128 * 10 >= (long)cu_count() * 6 ? 128 : 64;
+    *bn = skinny_count(a, 64, 128) * 10 >= fill ? 128 : 64;
 }
 
-// Does the small-batch kernel take this problem?  Plain / residual epilogues of the 16-bit modes whose gemm_kernel grid (128-row
-// tiles) would occupy at most a quarter of the CUs (at half, gemm_kernel is as fast or faster: 4096 x 640), with a K loop long
-// enough for the ring to matter.
+// Does the small-batch kernel take this problem?  Plain / residual epilogues of the 16-bit modes with a K loop long enough for the
+// ring to matter, when gemm_kernel's grid (128-row tiles) would occupy at most a quarter of the CUs, or when 128 x 128 tiles make
+// one round of 0.6 ... 1 workgroups per CU (2048 x 1280 x 11520: 0.132 against 0.146 ms; 4096 x 640: equal).
 bool gemm_skinny_applies(const GemmArgs& a) {
     if (a.epi == EPI_GEGLU || a.act != 0 || a.gate != nullptr || a.out_split) return false;
     if (a.K < 8 * 64 || a.K % 64 || a.C0 % 64 || (a.A1 && a.C1 % 64) || a.N % 8) return false;
@@ -244,7 +247,8 @@ bool gemm_skinny_applies(const GemmArgs& a) {
 #ifdef DSIM_DEVTOOLS
     if (g_gemm_skinny == 2) return reg_tiles <= 2 * cu_count();          // kbench: widen the rule for a sweep
 #endif
-    return reg_tiles * 4 <= cu_count();
+    const long c128 = skinny_count(a, 128, 128);
+    return reg_tiles * 4 <= cu_count() || (c128 * 10 >= (long)cu_count() * 6 && c128 <= cu_count());
 }
 
 // a: operand extents already filled in (launch_gemm does it)

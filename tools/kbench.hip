@@ -105,7 +105,7 @@ static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H,
     }
     if (getenv("KB_SKINNY") && atoi(getenv("KB_SKINNY")) == 2) g_gemm_skinny = 2;      // widened applies() rule for the sweep
     if (getenv("KB_SKINNY") && gemm_skinny_applies(g)) {      // small-batch kernel: gemm_kernel against every skinny tile (interleaved rounds)
-        const int tiles[5] = {-1, (64 << 8) | 64, (128 << 8) | 64, (64 << 8) | 128, (128 << 8) | 128};
+        const int tiles[6] = {-1, (64 << 8) | 64, (128 << 8) | 64, (64 << 8) | 128, (128 << 8) | 128, (128 << 8) | 160};
         const int rounds = getenv("KB_ROUNDS") ? atoi(getenv("KB_ROUNDS")) : 5;
         std::vector<std::vector<float>> ms(6);
         g_force_bm = 0;

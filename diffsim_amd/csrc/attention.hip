@@ -931,8 +931,10 @@ __global__ __launch_bounds__(256, (D <= 80 ? 4 : 2)) void attn_short_kernel(cons
 
 // ---- fused score tail ----------------------------------------------------------------------
 // grid (ceil(N/128), B*H, n_pairs*2); partial layout [pair][dir][bh][qtile][4] f32
+// (16-bit modes up to d = 80: held to two workgroups per CU -- left alone hipcc parks copies in AGPRs, 276 registers at d = 72, one
+//  wave per SIMD; d = 160 keeps both outputs in f32, 426 registers: forcing it to 256 spills 215 of them inside the key loop, 0.50 -> 0.85 ms)
 template <typename T, int D>
-__global__ __launch_bounds__(256) void pair_tail_kernel(const T* __restrict__ qg, const T* __restrict__ kg,
+__global__ __launch_bounds__(256, ((sizeof(T) == 2 && D <= 80) ? 2 : 1)) void pair_tail_kernel(const T* __restrict__ qg, const T* __restrict__ kg,
                                                         const T* __restrict__ vg, const int32_t* __restrict__ idx_a,
                                                         const int32_t* __restrict__ idx_b, int B, int H, int N,
                                                         float scale_log2, int mse, float* __restrict__ part) {

@@ -94,6 +94,15 @@ void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn) {
     if (want256) { *bm = 256; *bn = n320 ? 320 : (n256 ? 256 : 192); return; }
     *bm = 128;
     *bn = (a.N % 160 == 0 && !geglu) ? 160 : 128;
+    // 128 x 160 tiles that would leave ONE 4-wave workgroup per CU (<= CUs tiles: 4096 x 1280 = 16 batch elements at the 16 x 16
+    // level): half-width tiles put two on every CU -- conv 4096 x 1280 x 11520 0.163 -> 0.143 ms, x 23040 0.312 -> 0.281; where 128 x 160
+    // already gives two per CU they lose 35 % (profiles/r04_small_batch.txt)
+#ifdef DSIM_DEVTOOLS
+    const bool allow80 = !(g_gemm_exp & 2048);
+#else
+    const bool allow80 = true;
+#endif
+    if (allow80 && *bn == 160 && (long)((a.M + 127) / 128) * (a.N / 160) <= cu_count()) *bn = 80;
 }
 
 // The tile gemm_kernel is launched with (gemm_tile_choice + what the instantiation set allows): the f32 parity mode has
@@ -107,8 +116,9 @@ void gemm_launch_tile(const GemmArgs& a, int dtype, int* bm, int* bn) {
     if (big && slow && *bn == 320 && !act_only) big = false;
     if (!big) {
         const bool n160 = *bn == 160 || (a.epi == EPI_GEGLU && a.geglu_blk == 16);
+        const bool n80 = *bn == 80 && dtype != DSIM_F32 && !slow;          // (16-bit instantiations only; f32: the 160-column tile)
         *bm = 128;
-        *bn = slow ? 128 : (n160 ? 160 : 128);
+        *bn = slow ? 128 : (n80 ? 80 : ((n160 || *bn == 80) ? 160 : 128));
     }
 }
 
@@ -808,6 +818,8 @@ int launch_typed(const GemmArgs& a_in, hipStream_t s) {
     }
     if (slow) return launch_one<T, 128, 128, GEMM_LINEAR, false, 4, 1, true>(a, s);
     if (a.epi == EPI_GEGLU) return n160 ? launch_one<T, 128, 160, GEMM_LINEAR, true>(a, s) : launch_one<T, 128, 128, GEMM_LINEAR, true>(a, s);
+    if constexpr (sizeof(T) == 2)
+        if (bn == 80) return a.mode == GEMM_CONV3 ? launch_one<T, 128, 80, GEMM_CONV3, false>(a, s) : launch_one<T, 128, 80, GEMM_LINEAR, false>(a, s);
     if (a.mode == GEMM_CONV3)
         return n160 ? launch_one<T, 128, 160, GEMM_CONV3, false>(a, s) : launch_one<T, 128, 128, GEMM_CONV3, false>(a, s);
     return n160 ? launch_one<T, 128, 160, GEMM_LINEAR, false>(a, s) : launch_one<T, 128, 128, GEMM_LINEAR, false>(a, s);

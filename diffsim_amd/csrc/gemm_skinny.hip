@@ -19,20 +19,27 @@ namespace {
 
 constexpr int SNW = 4, SBK_BYTES = 128;
 
-// SBM x SBN tile (multiples of 32), 4 waves as 2 x 2; ring of SDEPTH slots (as many as fit in 144 KB, at most 8)
+// SBM x SBN tile, 4 waves as 2 x 2 (SBN a multiple of 32) or, for the 80-column tiles, as 4 x 1 (every wave SBM/4 rows x all columns);
+// ring of SDEPTH slots (as many as fit in 144 KB, at most 8).  The weight rows are staged in 32-row groups (8 rows per wave): an
+// 80-column tile stages 96, the last 16 as zero-filling out-of-range pieces so that every wave issues the same number of DMA
+// pieces per K tile (the counted vmcnt needs one number).
 template <int MODE, bool RES, int SBM, int SBN>
 __global__ __launch_bounds__(SNW * 64, 1) void gemm_skinny_kernel(const GemmArgs p, const int tilesN) {
     constexpr int BK = 64, ES = 2;
-    constexpr int SSTAGE = (SBM + SBN) * SBK_BYTES;
+    constexpr bool W41 = SBN % 32 != 0;                      // 4 x 1 wave layout
+    constexpr int WLM = W41 ? 4 : 2, WLN = 4 / WLM;
+    constexpr int SBNP = (SBN + 31) / 32 * 32;               // staged weight rows
+    constexpr int SSTAGE = (SBM + SBNP) * SBK_BYTES;
     constexpr int SDEPTH = (144 * 1024 / SSTAGE) < 8 ? (144 * 1024 / SSTAGE) : 8;      // SDEPTH - 1 K tiles in flight
-    constexpr int NAP = SBM / 32, NBP = SBN / 32;            // 8-row DMA pieces per wave per K tile: activation, weight
+    constexpr int NAP = SBM / 32, NBP = SBNP / 32;           // 8-row DMA pieces per wave per K tile: activation, weight
     constexpr int SPW = NAP + NBP;
-    constexpr int TM = SBM / 32, TN = SBN / 32;              // 16 x 16 accumulator tiles per wave (wave tile SBM/2 x SBN/2)
+    constexpr int TM = SBM / (16 * WLM), TN = SBN / (16 * WLN);      // 16 x 16 accumulator tiles per wave
+    static_assert(SBM % (16 * WLM) == 0 && SBN % (16 * WLN) == 0 && SBM % 32 == 0, "wave tile");
     static_assert(SDEPTH >= 3 && (SDEPTH - 2) * SPW <= 63, "ring");
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (scalar: the DMA pieces' LDS destinations need no v_readfirstlane)
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = W41 ? wave : wave >> 1, wn = W41 ? 0 : wave & 1;
     const int l15 = lane & 15, quad = lane >> 4, lrow = lane >> 3;
     const int wrow = wave * 8 + lrow;                                 // row inside a 32-row group of DMA pieces
     const unsigned celb = ((lane & 7) ^ ((wrow >> 1) & 7)) * 16;      // swizzled source chunk (gemm_kernel's LDS image)
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(SNW * 64, 1) void gemm_skinny_kernel(const GemmArgs
 #pragma unroll
     for (int i = 0; i < NBP; ++i) {
         const int n = n0 + i * 32 + wrow;
-        b_voff[i] = (n < p.N) ? (unsigned)n * (unsigned)p.K * (unsigned)ES + celb : OOB;
+        b_voff[i] = (n < p.N && i * 32 + wrow < SBN) ? (unsigned)n * (unsigned)p.K * (unsigned)ES + celb : OOB;
     }
     auto issue = [&](int t) {
         char* sa = smem + (t % SDEPTH) * SSTAGE;
@@ -105,18 +112,18 @@ __global__ __launch_bounds__(SNW * 64, 1) void gemm_skinny_kernel(const GemmArgs
                                                      (int)b_voff[i], k0 * ES, 0, 0);
     };
 
-    // D^T accumulators as in gemm_kernel: acc[i][j][r] = output row m0 + wm SBM/2 + 16 i + l15, column n0 + wn SBN/2 + 16 j + 4 quad + r.
+    // D^T accumulators as in gemm_kernel: acc[i][j][r] = output row m0 + wm SBM/WLM + 16 i + l15, column n0 + wn SBN/WLN + 16 j + 4 quad + r.
     // Linear layers start at the bias, the 3x3 conv adds it in f32 behind the K loop (gemm_kernel's BIAS_INIT rule).
     f32x4 acc[TM][TN];
     constexpr bool BIAS_INIT = MODE == GEMM_LINEAR;
     const int nk = p.K / BK;
     bool odd[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) odd[i] = p.bias2 && (((m0 + wm * (SBM / 2) + i * 16 + l15) / p.rows_per_batch) & 1);
+    for (int i = 0; i < TM; ++i) odd[i] = p.bias2 && (((m0 + wm * (SBM / WLM) + i * 16 + l15) / p.rows_per_batch) & 1);
     f32x4 b4[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int nb = n0 + wn * (SBN / 2) + j * 16 + 4 * quad;
+        const int nb = n0 + wn * (SBN / WLN) + j * 16 + 4 * quad;
         b4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
         if (p.bias && nb < p.N) {
@@ -141,8 +148,8 @@ __global__ __launch_bounds__(SNW * 64, 1) void gemm_skinny_kernel(const GemmArgs
         // s_barrier -- __syncthreads() would put vmcnt(0) in front of it and drain the ring
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (t + SDEPTH - 1 < nk) issue(t + SDEPTH - 1);               // into the slot K tile t - 1 has left
-        const char* sa = smem + (t % SDEPTH) * SSTAGE + wm * (SBM / 2) * 128;
-        const char* sb = smem + (t % SDEPTH) * SSTAGE + SBM * SBK_BYTES + wn * (SBN / 2) * 128;
+        const char* sa = smem + (t % SDEPTH) * SSTAGE + wm * (SBM / WLM) * 128;
+        const char* sb = smem + (t % SDEPTH) * SSTAGE + SBM * SBK_BYTES + wn * (SBN / WLN) * 128;
 #pragma unroll
         for (int step = 0; step < 2; ++step) {
             h16x8 xf[TM], wf[TN];
@@ -161,10 +168,10 @@ __global__ __launch_bounds__(SNW * 64, 1) void gemm_skinny_kernel(const GemmArgs
     const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual ? p.residual : p.out), 0, (int)p.out_bytes, 0x00020000);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * (SBM / 2) + i * 16 + l15;
+        const int m = m0 + wm * (SBM / WLM) + i * 16 + l15;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int nb = n0 + wn * (SBN / 2) + j * 16 + 4 * quad;
+            const int nb = n0 + wn * (SBN / WLN) + j * 16 + 4 * quad;
             const bool ok = m < p.M && nb < p.N;
             const unsigned off = ok ? ((unsigned)m * (unsigned)p.ldo + (unsigned)nb) * (unsigned)ES : OOB;
             float v[4];
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(SNW * 64, 1) void gemm_skinny_kernel(const GemmArgs
 
 template <int MODE, bool RES, int SBM, int SBN>
 int launch_skinny_t(const GemmArgs& g, hipStream_t s) {
-    constexpr int STG = (SBM + SBN) * SBK_BYTES;
+    constexpr int STG = (SBM + (SBN + 31) / 32 * 32) * SBK_BYTES;
     constexpr int LDS = ((144 * 1024 / STG) < 8 ? (144 * 1024 / STG) : 8) * STG;
     static DeviceOnce once;
     auto kern = gemm_skinny_kernel<MODE, RES, SBM, SBN>;
@@ -210,6 +217,8 @@ int launch_skinny(const GemmArgs& g, hipStream_t s) {
     if (bm == 128 && bn == 64) return launch_skinny_t<MODE, RES, 128, 64>(g, s);
     if (bm == 64 && bn == 128) return launch_skinny_t<MODE, RES, 64, 128>(g, s);
     if (bm == 128 && bn == 128) return launch_skinny_t<MODE, RES, 128, 128>(g, s);
+    if (bm == 64 && bn == 80) return launch_skinny_t<MODE, RES, 64, 80>(g, s);
+    if (bm == 128 && bn == 80) return launch_skinny_t<MODE, RES, 128, 80>(g, s);
 #ifdef DSIM_DEVTOOLS
     if (bm == 128 && bn == 160) return launch_skinny_t<MODE, RES, 128, 160>(g, s);     // kbench sweep only (never the heuristic's choice)
 #endif
@@ -222,25 +231,25 @@ int launch_skinny(const GemmArgs& g, hipStream_t s) {
 int g_skinny_tile = 0;          // kbench: 0 heuristic, else (bm << 8) | bn
 #endif
 
-// Tile of the small-batch kernel.  Per K tile a workgroup moves (bm + bn) x 128 B through its CU's L2 -> LDS path for
-// bm x bn x 64 MACs and one workgroup runs per CU (the ring fills LDS), so wider tiles move fewer bytes in total but leave CUs
-// idle.  Measured (tools/kbench KB_SKINNY=2, profiles/r04_small_batch.txt): the largest tile that still gives >= 0.6 workgroups
-// per CU wins -- 128 x 128 at 2048 x 1280 (160 workgroups: 0.132 ms against 0.188 for 64 x 128 and 0.146 for gemm_kernel),
-// 64 x 128 at 1024 x 1280 (0.103 against 0.146 / 0.148 for 64 x 64), 64 x 64 at 256 / 512 x 1280 (0.075 against 0.150); 128 x 64
-// is 5-10 % behind 64 x 128; more workgroups than CUs (a second round) always loses to gemm_kernel.
+// Tile of the small-batch kernel.  One workgroup runs per CU (the ring fills LDS) and streams (bm + bn) x 128 B per K tile through
+// its CU's L2 -> LDS path, so the tile with the smallest bm + bn that still makes ONE round (<= CUs workgroups) wins -- by less than
+// the byte count says once most CUs stream at the same time (the L2s' aggregate rate, ~8.7 TB/s, takes over).  Measured (tools/kbench
+// KB_SKINNY=2, profiles/r04_small_batch.txt), ms at K = 11520: 1024 x 1280: 64x80 (256 workgroups) 0.094 | 64x128 (160) 0.098 | 128x64
+// 0.105 | 128x128 (80) 0.133 | 64x64 (320: two rounds) 0.143 | gemm_kernel 0.124; 2048 x 1280: 128x80 (256) 0.123 | 128x128 (160) 0.135 |
+// 64x128 (320) 0.192 | gemm_kernel 0.131; 256 / 512 x 1280: 64x64 0.072 against 0.124.
 static long skinny_count(const GemmArgs& a, int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); }
+static const int kSkinnyTiles[5][2] = {{64, 64}, {64, 80}, {64, 128}, {128, 80}, {128, 128}};      // by bm + bn
 void gemm_skinny_tile(const GemmArgs& a, int* bm, int* bn) {
 #ifdef DSIM_DEVTOOLS
     if (g_skinny_tile) { *bm = g_skinny_tile >> 8; *bn = g_skinny_tile & 255; return; }
 #endif
-    const long fill = (long)cu_count() * 6;
-    if (skinny_count(a, 128, 128) * 10 >= fill) { *bm = 128; *bn = 128; return; }
-    *bm = 64;
-    *bn = skinny_count(a, 64, 128) * 10 >= fill ? 128 : 64;
+    for (const auto& t : kSkinnyTiles)
+        if (skinny_count(a, t[0], t[1]) <= cu_count() && (t[1] != 80 || a.N % 80 == 0)) { *bm = t[0]; *bn = t[1]; return; }
+    *bm = 128; *bn = 128;
 }
 
 // Does the small-batch kernel take this problem?  Plain / residual epilogues of the 16-bit modes with a K loop long enough for the
-// ring to matter, when gemm_kernel's grid (128-row tiles) would occupy at most a quarter of the CUs, or when 128 x 128 tiles make
+// ring to matter, when gemm_kernel's grid (128-row tiles) would occupy at most a quarter of the CUs, or when its best tile makes
 // one round of 0.6 ... 1 workgroups per CU (2048 x 1280 x 11520: 0.132 against 0.146 ms; 4096 x 640: equal).
 bool gemm_skinny_applies(const GemmArgs& a) {
     if (a.epi == EPI_GEGLU || a.act != 0 || a.gate != nullptr || a.out_split) return false;
@@ -249,8 +258,11 @@ bool gemm_skinny_applies(const GemmArgs& a) {
 #ifdef DSIM_DEVTOOLS
     if (g_gemm_skinny == 2) return reg_tiles <= 2 * cu_count();          // kbench: widen the rule for a sweep
 #endif
-    const long c128 = skinny_count(a, 128, 128);
-    return reg_tiles * 4 <= cu_count() || (c128 * 10 >= (long)cu_count() * 6 && c128 <= cu_count());
+    if (reg_tiles * 4 <= cu_count()) return true;
+    int bm, bn;
+    gemm_skinny_tile(a, &bm, &bn);
+    const long c = skinny_count(a, bm, bn);
+    return c * 10 >= (long)cu_count() * 6 && c <= cu_count();
 }
 
 // a: operand extents already filled in (launch_gemm does it)

@@ -105,22 +105,23 @@ static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H,
     }
     if (getenv("KB_SKINNY") && atoi(getenv("KB_SKINNY")) == 2) g_gemm_skinny = 2;      // widened applies() rule for the sweep
     if (getenv("KB_SKINNY") && gemm_skinny_applies(g)) {      // small-batch kernel: gemm_kernel against every skinny tile (interleaved rounds)
-        const int tiles[6] = {-1, (64 << 8) | 64, (128 << 8) | 64, (64 << 8) | 128, (128 << 8) | 128, (128 << 8) | 160};
+        const int tiles[8] = {-1, (64 << 8) | 64, (128 << 8) | 64, (64 << 8) | 128, (128 << 8) | 128, (128 << 8) | 160, (64 << 8) | 80, (128 << 8) | 80};
         const int rounds = getenv("KB_ROUNDS") ? atoi(getenv("KB_ROUNDS")) : 5;
-        std::vector<std::vector<float>> ms(6);
+        std::vector<std::vector<float>> ms(8);
         g_force_bm = 0;
         for (int r = 0; r < rounds; ++r)
-            for (int k = 0; k < 6; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 g_gemm_skinny = tiles[k] >= 0 ? (atoi(getenv("KB_SKINNY")) == 2 ? 2 : 1) : 0; g_skinny_tile = tiles[k] > 0 ? tiles[k] : 0;
                 ms[k].push_back(t.run([&] { st = launch_gemm(g, DSIM_BF16, 0); }, iters));
             }
         g_gemm_skinny = 1; g_skinny_tile = 0;
         int hb, hn;
         gemm_skinny_tile(g, &hb, &hn);
-        printf("  small-batch median ms: gemm_kernel %.4f | 64x64 %.4f | 128x64 %.4f | 64x128 %.4f | 128x128 %.4f | 128x160 %.4f | heuristic %dx%d\n",
+        printf("  small-batch median ms: gemm_kernel %.4f | 64x64 %.4f | 128x64 %.4f | 64x128 %.4f | 128x128 %.4f | 128x160 %.4f | 64x80 %.4f | 128x80 %.4f | heuristic %dx%d\n",
                (std::sort(ms[0].begin(), ms[0].end()), ms[0][rounds / 2]), (std::sort(ms[1].begin(), ms[1].end()), ms[1][rounds / 2]),
                (std::sort(ms[2].begin(), ms[2].end()), ms[2][rounds / 2]), (std::sort(ms[3].begin(), ms[3].end()), ms[3][rounds / 2]),
-               (std::sort(ms[4].begin(), ms[4].end()), ms[4][rounds / 2]), (std::sort(ms[5].begin(), ms[5].end()), ms[5][rounds / 2]), hb, hn);
+               (std::sort(ms[4].begin(), ms[4].end()), ms[4][rounds / 2]), (std::sort(ms[5].begin(), ms[5].end()), ms[5][rounds / 2]),
+               (std::sort(ms[6].begin(), ms[6].end()), ms[6][rounds / 2]), (std::sort(ms[7].begin(), ms[7].end()), ms[7][rounds / 2]), hb, hn);
     }
     if (const char* e = getenv("KB_GEXP")) {            // kernel experiment masks on the auto tile, e.g. KB_GEXP=32,64,128
         // interleaved rounds in one process (cdna_hip_programming.md rule 24): every mask (0 first) timed once per round, min and median

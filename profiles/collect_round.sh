@@ -18,7 +18,7 @@ done
 python3 - $T <<'PY'
 import json, os, sys
 tag = sys.argv[1]
-for suffix, model in (("", ""), ("_10k", ""), ("_two_streams", ""), ("_unfused", ""), ("_dedup_cfg", ""), ("_sdxl", "sdxl_"), ("_dit", "dit_"), ("_dit_fp8", "dit_")):
+for suffix, model in (("", ""), ("_10k", ""), ("_two_streams", ""), ("_unfused", ""), ("_dedup_cfg", ""), ("_pixels_in", ""), ("_sdxl", "sdxl_"), ("_dit", "dit_"), ("_dit_fp8", "dit_")):
     p = f"profiles/{tag}_bench{suffix}.json"
     hb, mf = f"profiles/{tag}_{model}pmc_hbm.json", f"profiles/{tag}_{model}pmc_mfma.json"
     if not (os.path.exists(p) and os.path.exists(hb) and os.path.exists(mf)):

@@ -33,8 +33,10 @@ int g_gemm_exp = 0;
 int g_gemm_skinny = 1;
 #endif
 // Tile choice.  Small problems: 128-row tiles, 4 waves, two workgroups per CU (160-wide when N
-// allows -- every SD channel count is a multiple of 160 -- else 128).  h16 problems with enough
-// 256-row tiles to fill the chip: 256 x 320 (or 256 x 256, or 256 x 192 for the DiT widths) tiles, 8 waves as 4 x 2.
+// allows -- every SD channel count is a multiple of 160 -- else 128; 80-wide where 160 would leave one workgroup per CU).  h16
+// problems with enough 256-row tiles to fill the chip: 256 x 320 (or 256 x 256, or 256 x 192 for the DiT widths) tiles, 8 waves as
+// 4 x 2.  Every choice below was made by timing the neighbouring choice on the shapes it serves (profiles/r04_experiments.txt items
+// 12-15, profiles/r04_small_batch.txt); gemm_launch_tile() maps the result onto the instantiations that exist.
 void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn) {
     const bool geglu = a.epi == EPI_GEGLU;
     if (geglu && a.geglu_blk == 16) {                      // 16-row [h | g] blocks: the 320 / 160-column tiles (N % 320 == 0)

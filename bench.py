@@ -64,6 +64,8 @@ def rocprof_name(fam: str) -> str:
             return f"attn_short_kernel<{d}>"
         if kind == "long":
             return f"attn_long_kernel<{d}, 0>"
+        if kind in ("q2", "q2fast"):
+            return f"attn_q2_kernel<{d}, {'true' if kind == 'q2fast' else 'false'}>"
         return f"attn_kernel<{t}, {d}, {'true' if kind == 'fast' else 'false'}>"
     if p[0] == "ff":
         return "ff_fused_kernel<0>"

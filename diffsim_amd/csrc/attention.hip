@@ -382,6 +382,155 @@ __device__ __forceinline__ void attend(const QFrags<T, D>& qfr, const T* kb, con
         for (int r = 0; r < 16; ++r) o[db][r] *= inv;
 }
 
+// attend() for TWO 32-row query blocks per wave (a workgroup = 256 queries): every K and V^T fragment read from LDS feeds both
+// blocks.  attend() reads one kilobyte of fragments per MFMA -- at full MFMA rate 256 B per clock per CU, twice the LDS port -- so
+// the one-block form tops out near half the matrix rate whatever else it does; this one halves the reads and the K / V staging per
+// query.  Same arithmetic per row as attend() (same tiles, same order): results are bit-identical to it.  16-bit types without the
+// K ones-column trick (d = 64: SDXL), double-buffered staging.
+template <typename T, int D, bool FAST>
+__device__ __forceinline__ void attend2(const QFrags<T, D> (&qfr)[2], const T* kb, const T* vb, int ldk, int Nk, char* lds,
+                                        OAcc<T, D> (&oacc)[2], float (&l_out)[2]) {
+    typedef ACfg<T, D> C;
+    static_assert(sizeof(T) == 2 && C::PIPE && !C::KONE, "attend2: 16-bit, double-buffered, no K ones column");
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+    f32x16 minit[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[q].b[db][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) minit[q][r] = 0.f;
+    }
+    const int ntiles = (Nk + KT - 1) / KT;
+    StageRegs<T, D> sr;
+    __syncthreads();
+    tile_init<T, D>(sr, lds, ldk, Nk, tid);
+    tile_load<T, D>(sr, kb, vb, ldk, 0, Nk);
+    __syncthreads();
+    char* const lds0 = lds;
+    const int i16 = lane & 15, g = lane >> 4;
+    const int trow = 4 * (g >> 1) + (i16 >> 2), tcol = 16 * (g & 1) + 4 * (i16 & 3);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        lds = lds0 + (kt & 1) * 2 * C::TILE;
+        tile_store<T, D>(lds, sr, kt * KT, Nk);
+        __syncthreads();
+        if (kt + 1 < ntiles) tile_load<T, D>(sr, kb, vb, ldk, (kt + 1) * KT, Nk);
+        f32x16 s[2][2];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            s[0][jb] = minit[0];
+            s[1][jb] = minit[1];
+            const char* krow = lds + (jb * 32 + l31) * C::RS + half * 8 * C::ES;
+#pragma unroll
+            for (int ks = 0; ks < C::NKS; ++ks) {
+                h16x8 kf;
+                lload_frag(kf, krow + ks * 16 * C::ES);
+                mma(kf, qfr[0].f[ks], s[0][jb]);
+                mma(kf, qfr[1].f[ks], s[1][jb]);
+            }
+        }
+        if (kt * KT + KT > Nk) {                           // ragged last tile only
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kv = kt * KT + jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (kv >= Nk) s[q][jb][r] = -INFINITY;
+                    }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float tmax = -INFINITY;
+            if (!FAST || kt == 0) {
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[q][jb][r]);
+                tmax = max_halves(tmax);
+            }
+            if (kt == 0 || (!FAST && !__all(tmax <= 0.f))) {
+                const float delta = kt == 0 ? tmax : fmaxf(tmax, 0.f);
+                m_run[q] += delta;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) minit[q][r] = -m_run[q];
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[q][jb][r] -= delta;
+                if (kt != 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    l_run[q] *= alpha;
+#pragma unroll
+                    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[q].b[db][r] *= alpha;
+                }
+            }
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[q][jb][r] = __builtin_amdgcn_exp2f(s[q][jb][r]);
+            if constexpr (!C::ONES) {
+                float psum = 0.f;
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) psum += s[q][jb][r];
+                l_run[q] += psum;
+            }
+        }
+        const char* vt = lds + C::TILEK;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                h16x8 pf[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[q][j] = (h16)s[q][jb][8 * s2 + j];
+                const char* vbase = vt + (jb * 32 + 16 * s2 + trow) * C::RSV + tcol * 2;
+#pragma unroll
+                for (int db = 0; db < C::NDB; ++db) {
+                    const char* pa = vbase + db * 64;
+                    const h16x4 lo = h16_ds_read_tr16_b64((pa));
+                    const h16x4 hi = h16_ds_read_tr16_b64((pa + 8 * C::RSV));
+                    h16x8 vf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                    oacc[0].b[db] = H16_MFMA_32x32x16(vf, pf[0], oacc[0].b[db], 0, 0, 0);
+                    oacc[1].b[db] = H16_MFMA_32x32x16(vf, pf[1], oacc[1].b[db], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        auto& o = oacc[q].b;
+        float l_tot;
+        if constexpr (C::ONES) {
+            constexpr int RB = D / 32, RR = D % 32;
+            constexpr int RH = (RR >> 2) & 1, REG = (RR & 3) + 4 * (RR >> 3);
+            const float mine = o[RB][REG];
+            const float other = __shfl_xor(mine, 32);
+            l_tot = (half == RH) ? mine : other;
+        } else {
+            l_tot = l_run[q] + __shfl_xor(l_run[q], 32);
+        }
+        l_out[q] = l_tot;
+        const float inv = 1.0f / l_tot;
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= inv;
+    }
+}
+
 // The fast form, checked: every row's denominator must be finite and sane (it is >= ~1 by construction: the row's own
 // tile-0 maximum contributes exp2(0)); otherwise some exp2 overflowed and the whole workgroup repeats the block exactly.
 // h16 only (the fp32 parity mode keeps the exact running maximum).
@@ -711,6 +860,56 @@ __global__ __launch_bounds__(256, 2) void attn_long_kernel(const AttnArgs p, con
     if (__syncthreads_or(bad)) {
         attend<T, D, false>(qf[0], (const T*)p.k + kvoff, (const T*)p.v + kvoff, p.ldk, p.Nk, smem, oa[0]);
         attend<T, D, false>(qf[1], (const T*)p.k + kvoff, (const T*)p.v + kvoff, p.ldk, p.Nk, smem, oa[1]);
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        if (q[qb] >= p.Nq) continue;
+        T* orow = (T*)p.out + ((size_t)b * p.Nq + q[qb]) * p.ldo + h * D;
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = db * 32 + 8 * g + 4 * half;
+                if (d < D) {
+                    h16x4 v4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v4[j] = (h16)oa[qb].b[db][4 * g + j];
+                    *reinterpret_cast<h16x4*>(orow + d) = v4;
+                }
+            }
+    }
+}
+
+// grid ceil(Nq/256) * H * B (1-D): attend2 -- a workgroup = 4 waves x 64 query rows (two 32-row blocks per wave)
+template <int D, bool FASTK>
+__global__ __launch_bounds__(256, 2) void attn_q2_kernel(const AttnArgs p, const float scale_log2) {
+    typedef h16 T;
+    typedef ACfg<T, D> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+    const int nqb = (p.Nq + 255) / 256;
+    int bid = blockIdx.x;
+    if (p.xcd_remap) {
+        const int nwg = gridDim.x, xcd = bid & 7, qq = nwg >> 3, r = nwg & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + slot;
+    }
+    const int qblk = bid % nqb, bh = bid / nqb;
+    const int h = bh % p.H, b = bh / p.H;
+    QFrags<T, D> qf[2];
+    int q[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        q[qb] = qblk * 256 + wave * 64 + qb * 32 + l31;
+        const int qc = q[qb] < p.Nq ? q[qb] : p.Nq - 1;
+        load_q<T, D>(qf[qb], (const T*)p.q + ((size_t)b * p.Nq + qc) * p.ldq + h * D, half, scale_log2);
+    }
+    const size_t kvoff = (size_t)(b % p.Bkv) * p.Nk * p.ldk + h * D;
+    OAcc<T, D> oa[2];
+    float l[2];
+    attend2<T, D, FASTK>(qf, (const T*)p.k + kvoff, (const T*)p.v + kvoff, p.ldk, p.Nk, smem, oa, l);
+    if constexpr (FASTK) {          // as attend_checked: a non-finite or absurd denominator sends the workgroup through the exact form
+        const int bad = !(l[0] > 0.25f && l[0] < DSIM_H16_LSUM_MAX) || !(l[1] > 0.25f && l[1] < DSIM_H16_LSUM_MAX);
+        if (__syncthreads_or(bad)) attend2<T, D, false>(qf, (const T*)p.k + kvoff, (const T*)p.v + kvoff, p.ldk, p.Nk, smem, oa, l);
     }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -1062,6 +1261,25 @@ int launch_attn_d(const AttnArgs& a, hipStream_t s) {
             return DSIM_OK;
         }
     }
+    if constexpr (sizeof(T) == 2 && D == 64) {
+        // two query blocks per wave (attend2; d = 80 would spill 82-175 registers): halves the LDS fragment reads that bound attn_kernel; worth it from 256 queries up
+        if (a.Nk > 96 && a.Nq >= 256 && g_attn_q2) {
+            const dim3 grid2(((a.Nq + 255) / 256) * a.H * a.B);
+            if (a.Nk >= g_attn_fast_min) {
+                static DeviceOnce o1;
+                auto k = attn_q2_kernel<D, true>;
+                CK_ONCE(o1, k, C::LDS);
+                hipLaunchKernelGGL(k, grid2, dim3(256), C::LDS, s, a, scale_log2_of(D));
+            } else {
+                static DeviceOnce o2;
+                auto k = attn_q2_kernel<D, false>;
+                CK_ONCE(o2, k, C::LDS);
+                hipLaunchKernelGGL(k, grid2, dim3(256), C::LDS, s, a, scale_log2_of(D));
+            }
+            DSIM_HIP_CHECK(hipGetLastError());
+            return DSIM_OK;
+        }
+    }
     if (sizeof(T) == 2 && a.Nk >= g_attn_fast_min) {
         static DeviceOnce oncef;
         auto kern = attn_kernel<T, D, true>;
@@ -1128,12 +1346,14 @@ int g_attn_fast_min = 1024;
 
 // Which kernel launch_attention picks for this problem, as the suffix of the profile family name (bench.py maps family names to
 // the symbols rocprofv3 prints): "_short" attn_short_kernel (keys resident in LDS), "_long" attn_long_kernel (two query blocks
-// per wave, pipelined), "_fast" attn_kernel with the fixed-reference softmax, "" attn_kernel with the exact running maximum.
+// per wave, pipelined), "_q2" / "_q2fast" attn_q2_kernel (two query blocks per wave sharing every fragment read; exact / fixed-reference
+// softmax), "_fast" attn_kernel with the fixed-reference softmax, "" attn_kernel with the exact running maximum.
 // Mirrors launch_attn_d's conditions (the development switches are 1 in the product).
 const char* attention_kernel_kind(const AttnArgs& a, int dtype) {
     if (dtype == DSIM_F32) return "";
     if ((a.D == 40 || a.D == 80 || (a.D == 64 && a.Nq <= 1024)) && a.Nk <= 96) return "_short";
     if (a.D == 40 && a.Nk >= 2048 && a.Nk % KT == 0) return "_long";
+    if (a.D == 64 && a.Nk > 96 && a.Nq >= 256) return a.Nk >= g_attn_fast_min ? "_q2fast" : "_q2";
     if (a.Nk >= g_attn_fast_min) return "_fast";
     return "";
 }

@@ -165,7 +165,10 @@ def test_layernorm(eng, dtype, M, C):
     # the short-key kernel (bf16, <= 96 keys, d = 40 / 80) with several query blocks per workgroup and a ragged last block
     (16, 2, 8, 4096 + 40, 77, 40), (32, 2, 8, 1024 + 7, 77, 80), (2, 2, 8, 512, 96, 40),
     # the pipelined long-key kernel (bf16, d = 40, keys a multiple of 64 and >= 2048) with a ragged last query block
-    (1, 1, 2, 300, 2112, 40), (2, 1, 3, 257, 2048, 40)])
+    (1, 1, 2, 300, 2112, 40), (2, 1, 3, 257, 2048, 40),
+    # two query blocks per wave sharing the fragment reads (16-bit, d = 64, >= 256 queries, > 96 keys): running-maximum and
+    # fixed-reference (>= 1024 keys) forms, ragged last query block, ragged last key tile, K / V shared between batch elements
+    (2, 2, 3, 256, 200, 64), (2, 1, 2, 300, 1024, 64), (1, 1, 2, 513, 1100, 64), (2, 2, 10, 1024, 1024, 64)])
 def test_attention(eng, dtype, B, Bkv, H, Nq, Nk, D):
     g = torch.Generator().manual_seed(Nq + Nk + D)
     q = torch.randn(B, Nq, H * D, generator=g) * 1.3

@@ -217,7 +217,7 @@ static void bench_attn(const char* name, int B, int Bkv, int H, int Nq, int Nk, 
         std::sort(q1.begin(), q1.end()); std::sort(q2.begin(), q2.end());
         printf("  running maximum %8.3f/%8.3f ms | fixed reference %8.3f/%8.3f ms (min/median)\n", q1[0], q1[rounds / 2], q2[0], q2[rounds / 2]);
     }
-    if (Nk >= 2048) {                             // one query block per wave (attn_kernel) against two (attn_long_kernel)
+    if (Nk >= 2048 || (D == 64 && Nk > 96)) {   // one query block per wave (attn_kernel) against two (attn_long_kernel)
         std::vector<float> q1, q2;
         for (int r = 0; r < rounds; ++r) {
             g_attn_q2 = 0;

@@ -460,6 +460,7 @@ int main(int argc, char** argv) {
     bench_attn("attn_cross_4096_d40", B2, 2, 8, 4096, 77, 40, iters, t);
     bench_attn("attn_cross_1024_d80", B2, 2, 8, 1024, 77, 80, iters, t);
     bench_attn("attn_cross_256_d160", B2, 2, 8, 256, 77, 160, iters, t);
+    bench_attn("attn_dit_256_d72", B2, B2, 16, 256, 256, 72, iters, t);
     bench_attn("attn_sdxl_self_4096_d64", B2, B2, 10, 4096, 4096, 64, iters, t);
     bench_attn("attn_sdxl_self_1024_d64", B2, B2, 20, 1024, 1024, 64, iters, t);
     bench_attn("attn_sdxl_cross_4096_d64", B2, 2, 10, 4096, 77, 64, iters, t);

@@ -454,6 +454,8 @@ int main(int argc, char** argv) {
     bench_gemm("lin_dit_fc1_act", GEMM_LINEAR, B2 * 256, 4608, 1152, 0, 0, EPI_NONE, iters, t, zp, 0, 1);
     bench_gemm("lin_dit_proj_gate_res", GEMM_LINEAR, B2 * 256, 1152, 1152, 0, 0, EPI_RESIDUAL, iters, t, zp, 0, 0, true);
     bench_gemm("lin_dit_fc2_gate_res", GEMM_LINEAR, B2 * 256, 1152, 4608, 0, 0, EPI_RESIDUAL, iters, t, zp, 0, 0, true);
+    bench_gemm("lin_dit_proj_res_nogate", GEMM_LINEAR, B2 * 256, 1152, 1152, 0, 0, EPI_RESIDUAL, iters, t, zp);      // the same shapes without the adaLN gate
+    bench_gemm("lin_dit_fc2_res_nogate", GEMM_LINEAR, B2 * 256, 1152, 4608, 0, 0, EPI_RESIDUAL, iters, t, zp);
     bench_attn("attn_self_4096_d40", B2, B2, 8, 4096, 4096, 40, iters, t);
     bench_attn("attn_self_1024_d80", B2, B2, 8, 1024, 1024, 80, iters, t);
     bench_attn("attn_self_256_d160", B2, B2, 8, 256, 256, 160, iters, t);

@@ -139,6 +139,7 @@ struct GemmArgs {
     unsigned a0_bytes = 0, a1_bytes = 0, w_bytes = 0, out_bytes = 0;   // filled by launch_gemm: operand extents for the buffer descriptors
 #ifdef DSIM_DEVTOOLS
     int exp = 0;                                // kernel experiments (tools/kbench)
+    unsigned long long* stamps = nullptr;       // -DDSIM_STAMPS builds: per-phase cycle sums of gemm_kernel (7 words)
 #endif
 };
 int launch_gemm(const GemmArgs& a, int dtype, hipStream_t s);
@@ -153,6 +154,7 @@ extern int g_gemm_persistent;   // 0 = one tile per workgroup
 extern int g_force_bm;          // 0 = heuristic; 128/256 force the row tile
 extern int g_gemm_exp;          // experiment mask passed to gemm_kernel
 extern int g_gemm_skinny;       // 0 = small problems through gemm_kernel as well
+extern unsigned long long* g_gemm_stamps;   // device buffer of gemm_kernel's phase stamps (-DDSIM_STAMPS builds)
 extern int g_skinny_tile;       // 0 = heuristic, else (bm << 8) | bn
 extern int g_gn_onepass;        // DSIM_GN_ONEPASS
 extern int g_ln_rows;           // DSIM_LN_ROWS

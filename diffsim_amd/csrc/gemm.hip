@@ -31,6 +31,7 @@ int g_force_bm = 0;
 int g_gemm_persistent = 1;
 int g_gemm_exp = 0;
 int g_gemm_skinny = 1;
+unsigned long long* g_gemm_stamps = nullptr;
 #endif
 // Tile choice.  Small problems: 128-row tiles, 4 waves, two workgroups per CU (160-wide when N
 // allows -- every SD channel count is a multiple of 160 -- else 128; 80-wide where 160 would leave one workgroup per CU).  h16
@@ -125,6 +126,18 @@ void gemm_launch_tile(const GemmArgs& a, int dtype, int* bm, int* bn) {
 }
 
 namespace {
+
+// In-kernel phase stamps (cdna_hip_programming.md section 7, "In-kernel stamps"): a -DDSIM_STAMPS diagnostic build of tools/kbench
+// only; the sums go to a buffer of their own (GemmArgs.stamps), never into an output.  No stamp executes in the product.
+#if defined(DSIM_DEVTOOLS) && defined(DSIM_STAMPS)
+#define STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_DECL unsigned long long st_[7] = {0, 0, 0, 0, 0, 0, 0}, sa_[6] = {0, 0, 0, 0, 0, 0}
+#define STAMP_ACC(i) sa_[i] += st_[(i) + 1] - st_[i]
+#else
+#define STAMP(t) do { } while (0)
+#define STAMP_DECL do { } while (0)
+#define STAMP_ACC(i) do { } while (0)
+#endif
 
 template <typename T> struct Traits;
 template <> struct Traits<h16> {
@@ -401,12 +414,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     constexpr bool BIAS_INIT = !CONV;
     const bool has_res = EK == EK_RES || (SLOW && p.epi == EPI_RESIDUAL);
 
+    STAMP_DECL;
     int vb = blockIdx.x;
     int tile_par = 0;                                   // parity of this workgroup's tile counter (bias buffer)
     int b0 = 0;                                         // staging buffer holding K stage 0 of the current tile
     setup(vb);
     stage(0, 0);
     while (true) {
+        STAMP(st_[0]);
         // 3x3 conv: the tile's bias slice goes to LDS here (80 lanes, one float4 each); the epilogue's register phase then reads
         // it with ds_read_b128 instead of 40 dependent global loads per tile, each behind a vmcnt(0) that also waited for the
         // next tile's first stage.  Buffer = tile parity: a wave is at most one tile ahead of the slowest (the barrier below).
@@ -453,8 +468,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                     for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
         }
         // stage 0 has landed in every wave; every wave is past the previous tile's epilogue (its LDS slabs are free)
+        STAMP(st_[1]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        STAMP(st_[2]);
         load_x(b0, 0, 0);
         load_w(b0, 0, 0);
         for (int t = 0; t < nk; ++t) {
@@ -477,6 +494,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
             mma_piece(2 * NP - 1);                              // the tile's last piece, from registers
             __builtin_amdgcn_sched_barrier(0);
         }
+        STAMP(st_[3]);
         const int xbuf = b0 ^ ((nk - 1) & 1);          // buffer the last K step read: epilogue scratch = it + spare
         const int em0 = m0, en0 = n0;
         const int nvb = vb + (int)gridDim.x;
@@ -485,6 +503,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
             setup(nvb);
             stage(0, xbuf ^ 1);
         }
+        STAMP(st_[4]);
     // ---- epilogue -------------------------------------------------------------------------
     // The accumulators hold D^T: lane = output row m (lane & 15), the four registers = output columns
     // n = 4 (lane >> 4) + r of a 16-wide block.  Each wave transposes one 16-row slab at a time
@@ -642,6 +661,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o16), rO, (int)off, 0, 0);
             }
         }
+        STAMP(st_[5]);
+        STAMP_ACC(0); STAMP_ACC(1); STAMP_ACC(2); STAMP_ACC(3); STAMP_ACC(4);
         if (!more) break;
         // the staging state was dead during the epilogue (registers!): re-derive it for the K loop.  The opaque
         // copy keeps the compiler from holding the pre-epilogue values live across the epilogue instead.
@@ -651,7 +672,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
         setup(vb);
         derive(0);
         b0 = xbuf ^ 1;
+        STAMP(st_[6]);
+        STAMP_ACC(5);
     }
+#if defined(DSIM_DEVTOOLS) && defined(DSIM_STAMPS)
+    // phase sums of this wave: [bias / accumulator init | loop-top wait + barrier | K loop | next tile's setup + first stage | epilogue | re-derive]
+    if (p.stamps && lane == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(p.stamps + i, sa_[i]);
+    if (p.stamps && tid == 0) atomicAdd(p.stamps + 6, 1ull);
+#endif
 }
 
 }  // namespace
@@ -724,6 +753,7 @@ int launch_ek(const GemmArgs& a, hipStream_t s) {
     }
 #ifdef DSIM_DEVTOOLS
     g.exp = g_gemm_exp;
+    g.stamps = g_gemm_stamps;
 #endif
     // persistent grid: as many workgroups as stay resident (LDS-limited), a multiple of 8 so a workgroup keeps its XCD
     const int ntiles = tilesM * tilesN;

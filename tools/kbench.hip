@@ -166,6 +166,26 @@ static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H,
         }
         printf("\n");
     }
+#ifdef DSIM_STAMPS
+    {   // phase stamps of gemm_kernel on the auto tile: share of a wave's cycles per phase
+        unsigned long long* sb;
+        HC(hipMalloc((void**)&sb, 64));
+        HC(hipMemset(sb, 0, 64));
+        g_force_bm = 0; g_gemm_stamps = sb;
+        st = launch_gemm(g, DSIM_BF16, 0);
+        HC(hipDeviceSynchronize());
+        g_gemm_stamps = nullptr;
+        unsigned long long h[8];
+        HC(hipMemcpy(h, sb, 64, hipMemcpyDeviceToHost));
+        double tot = 0;
+        for (int i = 0; i < 6; ++i) tot += (double)h[i];
+        static const char* nm[6] = {"init", "top-wait", "K-loop", "setup+stage0", "epilogue", "re-derive"};
+        printf("  stamps (%% of wave cycles, %llu workgroups):", h[6]);
+        for (int i = 0; i < 6; ++i) printf("  %s %.1f", nm[i], 100.0 * (double)h[i] / tot);
+        printf("\n");
+        HC(hipFree(sb));
+    }
+#endif
     int bm, bn;
     gemm_launch_tile(g, DSIM_BF16, &bm, &bn);
     printf("%-26s M=%7d N=%5d K=%5d  bm128 %7.3f ms %6.1f TF | bm256 %7.3f ms %6.1f TF | auto %dx%d %7.3f ms %6.1f TF st=%d\n",

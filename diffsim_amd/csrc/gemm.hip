@@ -23,6 +23,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace dsim {
 
@@ -198,10 +199,11 @@ constexpr int gemm_spare_bytes() {
     const int stage = (BM + BN) * 128, epi = gemm_epi_bytes<T, BM, BN, GEGLU, WM, WN>();
     return epi > stage ? ((epi - stage + 1023) / 1024) * 1024 : 0;
 }
-// + two f32 bias slices of the tile's BN columns (the conv epilogue reads its bias from LDS; buffer = tile parity)
+// + the bias of the tile's columns.  16-bit kernels: one 1-KB slot per wave and tile parity, filled by ONE LDS-DMA piece per wave
+// (the wave's own BN / WN columns) together with the tile's first K stage; f32: two slices of BN columns filled through registers.
 template <typename T, int BM, int BN, bool GEGLU, int WM, int WN>
 constexpr int gemm_lds_bytes() {
-    return 2 * (BM + BN) * 128 + gemm_spare_bytes<T, BM, BN, GEGLU, WM, WN>() + 2 * BN * 4;
+    return 2 * (BM + BN) * 128 + gemm_spare_bytes<T, BM, BN, GEGLU, WM, WN>() + (sizeof(T) == 2 ? 2 * WM * WN * 1024 : 2 * BN * 4);
 }
 
 // WM x WN waves; each owns a (BM/WM) x (BN/WN) sub-tile of 16 x 16 accumulator tiles, so an activation fragment is reused by
@@ -311,6 +313,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     // the first NBP % NW waves
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const bool b_tail = (NBP % NW == 0) || wave_u < (NBP % NW);
+    const int wm_u = wave_u / WN, wn_u = wave_u - wm_u * WN;       // the wave's position in the WM x WN layout, as scalars
+    // 16-bit kernels: the f32 bias of the wave's own BN / WN columns arrives by one LDS-DMA piece per wave and tile (issued with the
+    // tile's first K stage, i.e. a whole epilogue ahead; columns beyond N read as zeros through the descriptor's range check, as
+    // does everything when there is no bias).  The per-CFG-half bias2 of SDXL's resnets keeps the register path.
+    constexpr bool BDMA = sizeof(T) == 2;
+    static_assert(!BDMA || (BN / WN) * 4 <= 1024, "bias slot");
+    const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? (const void*)p.bias : p.W), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+    auto bias_dma = [&](int par) {       // slice of the tile setup() last ran for, into the slot of tile parity `par`
+        if (BDMA && !p.bias2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rBias, (__attribute__((address_space(3))) void*)(smem + 2 * STAGE + SPARE + (par * NW + wave_u) * 1024), 16,
+                                                     (int)((unsigned)(n0 + wn_u * (BN / WN)) * 4u + (unsigned)lane * 16u), 0, 0, 0);
+    };
 
     // K-tile t of the tile being staged: derive() refreshes the per-row offsets at a conv tap / second-source
     // boundary, issue() launches the LDS-DMA pieces of this wave into staging buffer `buf`
@@ -419,25 +433,36 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     int tile_par = 0;                                   // parity of this workgroup's tile counter (bias buffer)
     int b0 = 0;                                         // staging buffer holding K stage 0 of the current tile
     setup(vb);
+    bias_dma(0);
     stage(0, 0);
+    bool first = true;
+    constexpr int NST = TM * NIT;                       // stores a wave issues per epilogue
+    static_assert(NST <= 60, "counted vmcnt");
     while (true) {
         STAMP(st_[0]);
         // 3x3 conv: the tile's bias slice goes to LDS here (80 lanes, one float4 each); the epilogue's register phase then reads
         // it with ds_read_b128 instead of 40 dependent global loads per tile, each behind a vmcnt(0) that also waited for the
         // next tile's first stage.  Buffer = tile parity: a wave is at most one tile ahead of the slowest (the barrier below).
         // (bias2, the per-CFG-half bias of SDXL's resnets, keeps the global path.)
-        float* const bias_lds = reinterpret_cast<float*>(smem + 2 * STAGE + SPARE) + (tile_par ? BN : 0);
-        const bool bias_in_lds = !BIAS_INIT && p.bias && !p.bias2;
-        if (bias_in_lds && tid < BN / 4) {
+        // bias of this tile in LDS, indexed by the column relative to the tile's first (16-bit: the wave's own slot, shifted so that
+        // the same index works)
+        float* const bias_lds = BDMA ? reinterpret_cast<float*>(smem + 2 * STAGE + SPARE + (tile_par * NW + wave_u) * 1024) - wn_u * WBN
+                                     : reinterpret_cast<float*>(smem + 2 * STAGE + SPARE) + (tile_par ? BN : 0);
+        // (the 16-bit residual epilogue reads its bias from LDS unconditionally: zeros when there is none; check_args refuses bias2 there)
+        const bool bias_in_lds = !BIAS_INIT && (BDMA ? !p.bias2 : (p.bias && !p.bias2));
+        if (!BDMA && bias_in_lds && tid < BN / 4) {
             const int n = n0 + tid * 4;
             f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-            if (n < p.N) b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.bias && n < p.N) b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
             *reinterpret_cast<f32x4*>(bias_lds + tid * 4) = b4;
         }
-        // The accumulators start at the bias (f32) of their output column instead of zero: the epilogue then has no bias
-        // work at all.  (It used to fetch the bias in its register phase: 40 dependent global loads per tile, each followed
-        // by a vmcnt(0) that also drained the next tile's first stage and the residual prefetch.)  Here the TN loads of a
-        // tile fly while stage 0 lands.  D^T layout: register r of tile j is column n0 + wn*WBN + 16 j + 4 quad + r.
+        // 16-bit: this wave's pieces of stage 0 and its bias slice have landed once all but the previous epilogue's NST stores are
+        // done (they were issued before them): the stores' acknowledgements drain under K tile 0 instead of being waited for here
+        if constexpr (BDMA) {
+            if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST) : "memory");
+            first = false;
+        }
         if (BIAS_INIT && p.bias) {
             int ilane = lane;
             asm volatile("" : "+v"(ilane));                     // per-tile lane id: nothing derived from it stays live in the K loop
@@ -450,7 +475,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
             for (int j = 0; j < TN; ++j) {
                 const int nb = n0 + wn * WBN + j * 16 + 4 * iquad;
                 f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, c4 = {0.f, 0.f, 0.f, 0.f};
-                if (nb < p.N) {
+                if (BDMA && !p.bias2) {
+                    b4 = *reinterpret_cast<const f32x4*>(bias_lds + (nb - n0));
+                } else if (nb < p.N) {
                     b4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
                     if (p.bias2) c4 = *reinterpret_cast<const f32x4*>(p.bias2 + nb);
                 }
@@ -469,8 +496,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
         }
         // stage 0 has landed in every wave; every wave is past the previous tile's epilogue (its LDS slabs are free)
         STAMP(st_[1]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if constexpr (BDMA) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         STAMP(st_[2]);
         load_x(b0, 0, 0);
         load_w(b0, 0, 0);
@@ -501,6 +534,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
         const bool more = nvb < ntiles;
         if (more) {                                     // next tile's first stage flies during the epilogue
             setup(nvb);
+            bias_dma(tile_par ^ 1);
             stage(0, xbuf ^ 1);
         }
         STAMP(st_[4]);
@@ -525,15 +559,37 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
             ? __builtin_amdgcn_make_buffer_rsrc((char*)p.out + (size_t)osel * p.out_split_stride, 0, (int)p.out_bytes, 0x00020000) : rO;
         const int nout0 = (GEGLU ? (nw0 >> 1) : nw0) - osel * p.out_split;
         const int mw0 = em0 + wm * (BM / WM);
-        // byte offset of read-back piece `it` of slab i in the output (and residual) tensor; out-of-range
-        // rows / columns get an out-of-bounds buffer offset: loads return 0, stores are dropped -- no branches
-        auto out_off = [&](int ln, int i, int it) -> unsigned {
-            const int idx = ln + it * 64;
-            const int row = idx / CPR, c = idx - row * CPR;
-            const int m = mw0 + i * 16 + row, ncol = nout0 + c * VEC;
-            const bool ok = idx < 16 * CPR && m < p.M && ncol < Nout;
-            return ok ? ((unsigned)m * (unsigned)p.ldo + (unsigned)ncol) * (unsigned)ES : OOB;
-        };
+        // Addresses of the read-back pieces (round 5).  Piece `it` of slab i sits at
+        //     [uniform: ((mw0 + 16 i) ldo + nout0) ES]  +  [per lane, the same for every slab of the tile: (row(it) ldo + 8 c(it)) ES]
+        // so the uniform part rides in the buffer instruction's SCALAR offset and the lane part is formed once per tile: no vector
+        // arithmetic per piece (it was ~12 VALU per residual load and again per store: 240-480 per wave per tile, in an epilogue no
+        // MFMA overlaps).  Edges: on gfx950 the scalar offset takes part in the buffer range check (tools/soff_probe.hip), and the
+        // output / residual descriptors end at row M, so rows beyond M are dropped by the hardware; columns beyond N and the
+        // pieces beyond the slab's 16 rows carry an out-of-range lane part.
+        const int mw0_u = em0 + wm_u * (BM / WM);
+        const int nout0_u = (GEGLU ? ((en0 + wn_u * WBN) >> 1) : (en0 + wn_u * WBN)) - osel * p.out_split;
+        const int sbase = (mw0_u * p.ldo + nout0_u) * ES;               // scalar offset of slab 0
+        const int sslab = 16 * p.ldo * ES;                              // ... + i * sslab
+        unsigned lp[NIT];                                               // lane part of piece it
+        int lrd[NIT];                                                   // its 16 bytes in the wave's LDS slab
+        {
+            int plane = lane;
+            asm volatile("" : "+v"(plane));
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = plane + it * 64;
+                const int row = idx / CPR, c = idx - row * CPR;
+                lp[it] = (idx < 16 * CPR && nout0 + c * VEC < Nout) ? (unsigned)(row * p.ldo + c * VEC) * (unsigned)ES : OOB;
+                lrd[it] = (row < 16 ? row : 15) * RSO + c * 16;         // rows beyond the slab read a neighbouring row; their store is dropped
+            }
+        }
+        auto piece_v = [&](int, int, int it) -> unsigned { return lp[it]; };
+        auto piece_s = [&](int i) -> int { return sbase + i * sslab; };
+        // STORES add the scalar part to the vector offset instead (one v_add per piece): a buffer_store_dwordx4 with an SGPR soffset
+        // reads its data registers late on gfx950, and hipcc (which pads the next VALU write of a wide store's data registers only
+        // for a constant soffset) then lets e.g. the next piece's address arithmetic overwrite the first data dword -- seen as
+        // address-like garbage in the first 4 bytes of 16-byte pieces, on the later-dispatched waves, timing dependent.
+        auto store_v = [&](int i, int it) -> unsigned { return lp[it] == OOB ? OOB : lp[it] + (unsigned)(sbase + i * sslab); };
         // residual prefetch: slab i's 16-byte pieces are requested before slab i is transposed, so the HBM latency
         // hides under the register phase instead of serialising the stores (at most 10 pieces in flight per lane:
         // the f32 parity mode would spill with all 20)
@@ -543,8 +599,66 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 if (it >= it0 && it < it1)
-                    rres[i][it] = __builtin_amdgcn_raw_buffer_load_b128(rR, (int)out_off(elane, i, it), 0, 0);
+                    rres[i][it] = __builtin_amdgcn_raw_buffer_load_b128(rR, (int)piece_v(elane, i, it), piece_s(i), 0);
         };
+        // 16-bit residual epilogue (round 5): the WHOLE tile's residual is requested up front.  The accumulators are rounded to the
+        // 16-bit type first (their values leave through LDS in that type anyway: same rounding points as the slab-by-slab form), which
+        // halves their registers; the freed half takes all TM x NIT residual pieces in flight at once, so the tile pays the HBM
+        // latency of its residual once, under the conversions, instead of once per 16-row slab (profiles/r05_experiments.txt item 2:
+        // the slab-by-slab form was 31-42 % of a K = N <= 1280 launch against 12-17 % for the plain epilogue).
+        constexpr bool RES16 = EK == EK_RES && sizeof(T) == 2 && !GEGLU && CONV;      // (linears: the slab-by-slab form measured 1-3 % faster)
+        if constexpr (RES16) {
+            h16x4 pk[TM][TN];
+            constexpr int HP = TM >= 2 ? TM / 2 : 1;               // slabs per half: pack a half, request its residual, pack the other half
+#pragma unroll
+            for (int h0 = 0; h0 < TM; h0 += HP) {
+                // (an opaque offset per half: hipcc otherwise reads the ten bias vectors once and spills them across the residual loads)
+                int boff = (wn * WBN + 4 * equad) * 4;
+                asm volatile("" : "+v"(boff));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (!BIAS_INIT) b4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(bias_lds) + boff + j * 64);
+#pragma unroll
+                    for (int i = h0; i < h0 + HP; ++i) {
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = BIAS_INIT ? acc[i][j][e] : acc[i][j][e] + b4[e];
+                        const h16x2 lo = __builtin_convertvector((f32x2){v[0], v[1]}, h16x2), hi = __builtin_convertvector((f32x2){v[2], v[3]}, h16x2);
+                        pk[i][j] = (h16x4){lo[0], lo[1], hi[0], hi[1]};
+                        // pinned here: left alone hipcc sinks the conversions below the residual loads and keeps the f32 accumulators
+                        // (and, spilled, the bias vectors) live across them
+                        asm volatile("" : "+v"(pk[i][j]) :: "memory");
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = h0; i < h0 + HP; ++i) prefetch(i, 0, NIT);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    *reinterpret_cast<h16x4*>(wst + el15 * RSO + (j * 16 + 4 * equad) * ES) = pk[i][j];
+                int slane = lane;
+                asm volatile("" : "+v"(slane));
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const V16 t = *reinterpret_cast<const V16*>(wst + lrd[it]);
+                    const V16 r = __builtin_bit_cast(V16, rres[i][it]);
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    V16 o16;
+#pragma unroll
+                    for (int e = 0; e < VEC; e += 2) {
+                        const h16x2 pr = __builtin_convertvector((f32x2){(float)t[e] + (float)r[e], (float)t[e + 1] + (float)r[e + 1]}, h16x2);
+                        o16[e] = pr[0]; o16[e + 1] = pr[1];
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o16), rO, (int)store_v(i, it), 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             __builtin_amdgcn_sched_barrier(0);      // keep slab i+1's loads from being hoisted above slab i (spills)
@@ -602,14 +716,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
             asm volatile("" : "+v"(slane));
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int idx = slane + it * 64;
-                const int row = idx / CPR, c = idx - row * CPR;
-                const unsigned off = out_off(slane, i, it);
-                // rows beyond the slab (idx >= 16*CPR) read a neighbouring wave's LDS slab; their store is dropped
-                const int rrow = row < 16 ? row : 15;
-                const V16 t = *reinterpret_cast<const V16*>(wst + rrow * RSO + c * 16);
+                const V16 t = *reinterpret_cast<const V16*>(wst + lrd[it]);
                 if (!SLOW && !ACT && !has_res) {         // plain projection: LDS -> HBM copy
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rOt, (int)off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rOt, (int)store_v(i, it), 0, 0);
                     continue;
                 }
                 float v[VEC];
@@ -627,6 +736,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                     }
                 }
                 if (SLOW && p.gate) {
+                    const int idx = slane + it * 64;
+                    const int row = idx / CPR, c = idx - row * CPR, rrow = row < 16 ? row : 15;
                     const int m = mw0 + i * 16 + rrow, ncol = nout0 + c * VEC;
                     if (ncol < Nout) {
                         // which CFG half the row belongs to: one division per 16-row slab when the halves are 16-row
@@ -658,8 +769,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) o16[e] = (T)v[e];
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o16), rO, (int)off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o16), rO, (int)store_v(i, it), 0, 0);
             }
+        }
         }
         STAMP(st_[5]);
         STAMP_ACC(0); STAMP_ACC(1); STAMP_ACC(2); STAMP_ACC(3); STAMP_ACC(4);
@@ -789,6 +901,7 @@ int check_args(const GemmArgs& a, int BK) {
     if (a.epi == EPI_GEGLU && (a.mode != GEMM_LINEAR || (a.geglu_blk == 16 ? a.N % 320 != 0 : (a.geglu_blk != 32 || a.N % 64))))
         return DSIM_ERR_INVALID;
     if (!a.zero_page) return DSIM_ERR_INVALID;
+    if (a.mode == GEMM_CONV3 && a.epi == EPI_RESIDUAL && a.bias2) return DSIM_ERR_INVALID;      // per-half bias: plain convs only (conv1 of a resnet)
     if (a.out_split && (a.mode != GEMM_LINEAR || a.epi != EPI_NONE || a.act || a.gate || a.out_split % 320 || a.N % a.out_split ||
                         a.out_split_stride <= 0 || (a.N / a.out_split) * a.out_split_stride >= 0x7fffffffll))
         return DSIM_ERR_INVALID;

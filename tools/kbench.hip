@@ -37,6 +37,13 @@ __global__ void maxdiff_kernel(const __bf16* a, const __bf16* b, size_t n, float
     atomicMax(reinterpret_cast<int*>(out), __float_as_int(m));
 }
 // bitwise difference count of two buffers (tile-order experiments must not change a single output bit)
+// order-independent checksum of a 16-bit buffer (outputs of two builds of the library must agree bit for bit)
+__global__ void checksum_kernel(const unsigned short* a, size_t n, unsigned long long* out) {
+    unsigned long long c = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        c += (unsigned long long)a[i] * (unsigned long long)((i * 2654435761ull) | 1ull);
+    atomicAdd(out, c);
+}
 __global__ void bitdiff_kernel(const unsigned short* a, const unsigned short* b, size_t n, unsigned* out) {
     unsigned c = 0;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += a[i] != b[i];
@@ -188,8 +195,20 @@ static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H,
 #endif
     int bm, bn;
     gemm_launch_tile(g, DSIM_BF16, &bm, &bn);
-    printf("%-26s M=%7d N=%5d K=%5d  bm128 %7.3f ms %6.1f TF | bm256 %7.3f ms %6.1f TF | auto %dx%d %7.3f ms %6.1f TF st=%d\n",
-           name, M, N, K, msv[0], fl / msv[0] / 1e9, msv[1], fl / msv[1] / 1e9, bm, bn, msv[2], fl / msv[2] / 1e9, st);
+    unsigned long long csum = 0;
+    {
+        unsigned long long* dc;
+        HC(hipMalloc((void**)&dc, 8));
+        HC(hipMemset(dc, 0, 8));
+        g_force_bm = 0;
+        HC(hipMemset(out, 0xff, (size_t)M * outc * 2));
+        st = launch_gemm(g, DSIM_BF16, 0);
+        hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(256), 0, 0, (const unsigned short*)out, (size_t)M * outc, dc);
+        HC(hipMemcpy(&csum, dc, 8, hipMemcpyDeviceToHost));
+        HC(hipFree(dc));
+    }
+    printf("%-26s M=%7d N=%5d K=%5d  bm128 %7.3f ms %6.1f TF | bm256 %7.3f ms %6.1f TF | auto %dx%d %7.3f ms %6.1f TF st=%d sum=%016llx\n",
+           name, M, N, K, msv[0], fl / msv[0] / 1e9, msv[1], fl / msv[1] / 1e9, bm, bn, msv[2], fl / msv[2] / 1e9, st, csum);
     HC(hipFree(A)); if (A1) HC(hipFree(A1)); HC(hipFree(Wt)); HC(hipFree(bias)); HC(hipFree(res)); HC(hipFree(out));
 }
 

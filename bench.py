@@ -33,6 +33,7 @@ from diffsim_amd import scheduler as sched   # noqa: E402
 from diffsim_amd import synth as S           # noqa: E402
 
 GFLOP_PER_PAIR = 1580.4          # 4 x 197.2146 GMAC x 2 + 2.684 (tail)
+GFLOP_PER_PAIR_PIXELS = 3813.7   # + the VAE encoder of both images: 2 x 558.33 GMAC x 2
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBPS = 8000.0
@@ -41,6 +42,8 @@ TAP_KEYS_EXCLUDE = ("up_blocks.2", "up_blocks.3", "conv_norm_out", "conv_out")
 
 # kernel family (dsim_*_profile_get) -> symbol rocprofv3 --kernel-trace prints
 def rocprof_name(fam: str) -> str:
+    if fam.startswith("vae_"):                        # the VAE encoder's launches of a --pixels-in profile: same kernel symbols
+        return rocprof_name(fam[4:])
     p = fam.split("_")
     if p[0] == "gemm" and p[1] == "small":           # gemm_small_<dt>_<bm>x<bn>_<mode>[_res]: the small-batch kernel (gemm_skinny.hip)
         bm, bn = p[3].split("x")
@@ -255,7 +258,22 @@ def cpu_baseline_sd15(cfg, sd, lats, noise, gpu_scores, n_pairs):
     cpu_full_s = time.perf_counter() - tc
     g = [float(x) for x in gpu_scores[:n_pairs].float().cpu()]
     errs = [abs(a_ - b_) for a_, b_ in zip(g, cpu_scores)]
+    rel = lambda a_, b_: abs(a_ - b_) / max(abs(b_), 1e-6)
+    # the north_star tolerance, in the driver-run line: the SAME pairs through the fp32 kernel mode (exact-f32 MFMA chains) against
+    # the CPU oracle scores just computed; the run fails above 1e-4 relative
+    from diffsim_amd.diffsim import DiffSim
+    ds32 = DiffSim(torch_dtype=torch.float32, device="cuda", unet_config=cfg, state_dict=sd, dedup_cfg=False)
+    la = torch.cat([lats[i][0] for i in range(n_pairs)]).cuda()
+    lb = torch.cat([lats[i][1] for i in range(n_pairs)]).cuda()
+    g32 = [float(x) for x in ds32.score_latent_pairs(la, lb, noise[2].cuda(), noise[3].cuda(), ctx, "up_blocks", 0, 600, "cosine",
+                                                      batch_pairs=n_pairs, streams=1).float().cpu()]
+    del ds32
+    torch.cuda.empty_cache()
+    rel32 = [rel(a_, b_) for a_, b_ in zip(g32, cpu_scores)]
     return {
+        "parity_fp32": {"gpu": [round(x, 7) for x in g32], "cpu_oracle": [round(x, 7) for x in cpu_scores],
+                        "max_rel_err": max(rel32), "tolerance": 1e-4, "pass": max(rel32) <= 1e-4,
+                        "what": "the %d CPU-baseline pairs through the fp32 kernel mode (exact-f32 MFMA) against the fp32 CPU oracle" % n_pairs},
         "cpu_baseline": {"value": round(n_pairs / cpu_s, 5), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
                          "sample": "%d pairs (the first pairs of the batch; BASELINE config[0] = 4 pairs), one pair per call, fp32 "
                                    "torch CPU oracle, U-Net truncated at the tap, %.1f s of CPU work" % (n_pairs, cpu_s),
@@ -264,8 +282,36 @@ def cpu_baseline_sd15(cfg, sd, lats, noise, gpu_scores, n_pairs):
                          "reference_schedule": "pair 0, full U-Net to conv_out as diffsim_pipeline.py:213 runs it "
                                                "(score %.6f, %.1f s)" % (float(so_full), cpu_full_s)},
         "parity_vs_cpu_oracle": {"gpu": [round(x, 6) for x in g], "cpu_oracle": [round(x, 6) for x in cpu_scores],
-                                 "max_abs_err": max(errs)},
+                                 "max_abs_err": max(errs), "max_rel_err": max(rel(a_, b_) for a_, b_ in zip(g, cpu_scores))},
     }
+
+
+def product_default_leg(cfg, sd, dtype, dev, lats, noise, ctx, headline_value):
+    """What a user of INTEGRATION.md Option A gets: a DiffSim built with NO knobs (its defaults: CFG halves de-duplicated --
+    bit-identical scores -- and the chunk size / two streams score_latent_pairs picks itself) scoring the resident pairs through
+    `score_latent_pairs`, timed like the headline (warm call, then two timed calls over all resident pairs)."""
+    from diffsim_amd.diffsim import DiffSim
+    ds = DiffSim(torch_dtype=dtype, device=str(dev), unet_config=cfg, state_dict=sd)
+    la = torch.cat([p[0] for p in lats]).to(dev)
+    lb = torch.cat([p[1] for p in lats]).to(dev)
+    nA, nB = noise[2].to(dev), noise[3].to(dev)
+    run = lambda: ds.score_latent_pairs(la, lb, nA, nB, ctx)
+    s0 = run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        s0 = run()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    v = reps * len(lats) / el
+    del ds
+    torch.cuda.empty_cache()
+    return {"value_product_default": round(v, 3),
+            "product_default": {"pairs_per_call": len(lats), "calls_timed": reps, "vs_headline": round(v / headline_value, 4),
+                                "what": "DiffSim(dtype, device, unet_config, state_dict).score_latent_pairs(latA, latB, noiseA, noiseB, ctx) "
+                                        "with no other argument: dedup_cfg on (bit-identical scores), auto chunk, two streams",
+                                "score_sample": [round(float(x), 6) for x in s0[:2].float().cpu()]}}
 
 
 def secondary(a, world, rank, dev):
@@ -451,8 +497,8 @@ def headline(a, world, rank, dev):
                                   (", CFG halves de-duplicated up to the first cross-attention" if a.dedup_cfg else "")),
                    "pairs_per_step_per_gpu": bp * NS, "concurrent_sub_batches": NS, "pairs_per_sub_batch": bp,
                    "distinct_pairs_resident_per_gpu": bp * (1 if a.pixels_in else NB),
-                   "gflop_per_pair": GFLOP_PER_PAIR, "parallelism": f"pairs sharded x{world}"},
-        "whole_path_tflops_per_gpu": round(pairs_per_s / world * GFLOP_PER_PAIR / 1e3, 2),
+                   "gflop_per_pair": GFLOP_PER_PAIR_PIXELS if a.pixels_in else GFLOP_PER_PAIR, "parallelism": f"pairs sharded x{world}"},
+        "whole_path_tflops_per_gpu": round(pairs_per_s / world * (GFLOP_PER_PAIR_PIXELS if a.pixels_in else GFLOP_PER_PAIR) / 1e3, 2),
         "score_sample": [round(float(x), 6) for x in scores[:4].float().cpu()],
     }
     if rank == 0:
@@ -461,19 +507,36 @@ def headline(a, world, rank, dev):
             # ---- roofline of the dominant kernel: HIP events around every launch of one more step
             eng.profile(True)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            q, k, v = eng.qkv(lat_all[0], nz, sa, sb, ctx, out=qkv)
+            vrecs = []
+            if a.pixels_in:
+                # the VAE encoder's launches first (family names prefixed vae_: its 512 x 512-level kernels are the pixels-in path's own)
+                vae.profile(True)
+                z = latent_sample(vae.moments(imgs), eps, 0.18215)
+                vrecs = [("vae_" + r[0],) + tuple(r[1:]) for r in vae.profile_records(detail=True)]
+                vae.profile(False)
+                q, k, v = eng.qkv(z, nz, sa, sb, ctx, out=qkv)
+            else:
+                q, k, v = eng.qkv(lat_all[0], nz, sa, sb, ctx, out=qkv)
             e0.record()
             pair_score(q, k, v, ia, ib, eng.heads, "cosine")
             e1.record()
-            recs = eng.profile_records(detail=True)
+            recs = vrecs + eng.profile_records(detail=True)
             eng.profile(False)
+            if a.pixels_in:
+                vms = sum(r[3] for r in vrecs)
+                out["vae_ms_per_image"] = round(vms / (2 * bp), 4)
+                out["vae_tflops"] = round(sum(r[1] for r in vrecs) / (vms * 1e-3) / 1e12, 1)
             tail_ms = e0.elapsed_time(e1)
             out.update(roofline_fields(recs, peak, tail={"n": 2, "ms": round(tail_ms, 3),
                                                          "tflops": round(bp * 2.684e9 / (tail_ms * 1e-3) / 1e12, 1)},
                                        dump=a.dump_launches))
+        if world == 1 and not a.pixels_in and not a.no_product_default:
+            out.update(product_default_leg(cfg, sd, dtype, dev, lats, noise, ctx, pairs_per_s))
         if world == 1 and not a.no_cpu_baseline:
             out.update(cpu_baseline_sd15(cfg, sd, lats, noise, scores, a.cpu_pairs))
         print(json.dumps(out), flush=True)
+        if "parity_fp32" in out and not out["parity_fp32"]["pass"]:
+            raise SystemExit("bench.py: fp32 kernel mode is %.3g relative from the CPU oracle (tolerance 1e-4)" % out["parity_fp32"]["max_rel_err"])
 
 
 def main():
@@ -495,6 +558,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=4, help="pairs the CPU baseline leg scores (config[0] has 4)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-product-default", action="store_true",
+                    help="skip the secondary leg that scores the resident pairs through DiffSim.score_latent_pairs with no knobs")
     ap.add_argument("--dump-launches", type=str, default=None, help="write the per-launch records of the profiled step (JSON lines)")
     ap.add_argument("--model", choices=["sd15", "sdxl", "dit"], default="sd15",
                     help="sd15 = the headline metric (BASELINE config[1]); sdxl / dit = secondary lines for configs[3], [4]")

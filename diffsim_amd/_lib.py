@@ -83,6 +83,9 @@ SYMBOLS = {
     "dsim_vae_finalize": (_i, [_vp, _vp]),
     "dsim_vae_workspace_bytes": (_sz, [_vp, _i, _i]),
     "dsim_vae_encode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "dsim_vae_profile": (_i, [_vp, _i]),
+    "dsim_vae_profile_count": (_i, [_vp]),
+    "dsim_vae_profile_get": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dsim_image_preprocess": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dsim_latent_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "dsim_dit_create": (_i, [C.POINTER(DiTCfgC), C.POINTER(_vp)]),
@@ -126,7 +129,7 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.dsim_version() != 6:
+        if L.dsim_version() != 7:
             raise DsimError("ABI version mismatch")
         _lib = L
     return _lib

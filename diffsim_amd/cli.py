@@ -24,7 +24,7 @@ ENGINE_METRICS = ("diffsim", "diffsim_xl", "dit")
 
 
 def build_parser() -> argparse.ArgumentParser:
-    p = argparse.ArgumentParser(prog="python -m diffsim_amd", description="DiffSim scoring (MI355X-native engine)")
+    p = argparse.ArgumentParser(prog="python -m diffsim_amd", description="DiffSim scoring (MI355X-native engine)", allow_abbrev=False)
     p.add_argument("--image_path", type=str, help="Path to image folder")
     p.add_argument("--original_path", type=str, default=None, help="Path to original images for ipref")
     p.add_argument("--out_path", type=str, help="Path to the output folder")
@@ -50,13 +50,16 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--noise_dtype", type=str, choices=["fp32", "fp16"], default="fp32",
                    help="generator draws / add_noise arithmetic: fp32 pipeline or the reference's literal fp16 pipeline")
     p.add_argument("--batch", type=int, default=10, help="triplets per engine batch")
-    p.add_argument("--ngpu", type=int, default=1, help="GPUs of this node to shard the triplets over (one process each)")
+    p.add_argument("--ngpu", type=int, default=None,
+                   help="GPUs of this node to shard the triplets over (one process each); default 1, or the launcher's rank count")
     p.add_argument("--decode_procs", type=str, default="auto",
                    help="worker processes that decode + resize the image files ahead of the GPU: a number, 0 = threads of this "
                         "process, auto = host cores / ranks of the node")
     p.add_argument("--fp8_attention", action="store_true", help="--metric dit: e4m3 MFMA attention")
-    p.add_argument("--dedup_cfg", action="store_true",
-                   help="--metric diffsim: compute what the two CFG halves share once per image (bit-identical scores, ~6 %% faster)")
+    p.add_argument("--dedup_cfg", dest="dedup_cfg", action="store_true", default=True,
+                   help="--metric diffsim: compute what the two CFG halves share once per image (bit-identical scores, ~6 %% faster); the default")
+    p.add_argument("--no_dedup_cfg", dest="dedup_cfg", action="store_false",
+                   help="--metric diffsim: run the reference's duplicated CFG batch through every layer")
     return p
 
 
@@ -217,14 +220,16 @@ def main(argv=None) -> int:
         # --ngpu counts the GPUs of THIS node: under a launcher that is LOCAL_WORLD_SIZE (WORLD_SIZE on one node).  A launch
         # that left --ngpu at its default adopts the launcher's count; an explicit, different --ngpu is refused as mislabelled.
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"]))
-        explicit = any(a == "--ngpu" or a.startswith("--ngpu=") for a in argv)
+        explicit = args.ngpu is not None            # (default None: every spelling argparse accepts counts as given)
         if not explicit:
-            if local_world != args.ngpu:
+            if local_world != 1:
                 print(f"diffsim_amd: --ngpu not given; using the launcher's {local_world} rank(s) on this node", file=sys.stderr)
             args.ngpu = local_world
         elif local_world != args.ngpu:
             raise SystemExit(f"--ngpu {args.ngpu} but the launcher started {local_world} rank(s) on this node "
                              f"(LOCAL_WORLD_SIZE / WORLD_SIZE): refusing to run a mislabelled launch")
+    if args.ngpu is None:
+        args.ngpu = 1
     if args.ngpu > 1 and "WORLD_SIZE" not in os.environ:
         from .parallel import spawn_ranks              # the parent never touches the GPU
         return spawn_ranks(args.ngpu, [sys.executable, "-m", "diffsim_amd"] + argv)

@@ -937,6 +937,8 @@ int launch_typed(const GemmArgs& a_in, hipStream_t s) {
     if (slow && (a.mode != GEMM_LINEAR || a.epi == EPI_GEGLU)) return DSIM_ERR_INVALID;
     int bm, bn;
     gemm_launch_tile(a, sizeof(T) == 2 ? DSIM_H16 : DSIM_F32, &bm, &bn);
+    // out_split: the epilogue picks ONE destination tensor per tile from its first column, so the tile width must divide the split
+    if (a.out_split && a.out_split % bn != 0) return DSIM_ERR_INVALID;
     const bool big = bm == 256, n160 = bn == 160;
     (void)big;
     if constexpr (sizeof(T) == 2) {

@@ -98,6 +98,50 @@ struct WeightStore {
     }
 };
 
+// profile family of a GEMM launch = the kernel symbol launch_gemm will pick for it (one family per symbol), + its algorithmic work
+static inline std::string gemm_family(const GemmArgs& g, int dt, double* flops, double* bytes) {
+    int bm, bn;
+    gemm_launch_tile(g, dt, &bm, &bn);
+    const bool skinny = dt != DSIM_F32 && gemm_skinny_applies(g);      // the small-batch kernel (gemm_skinny.hip)
+    // 256-row 16-bit conv tiles on power-of-two output maps run the CONV3P instantiation (gemm.hip launch_typed)
+    const int hwo = g.Hout * g.Wout;
+    const bool conv_p2 = g.mode == GEMM_CONV3 && !skinny && dt != DSIM_F32 && bm == 256 && bn != 128 && g.Wout > 0 &&
+                         !(g.Wout & (g.Wout - 1)) && !(hwo & (hwo - 1));
+    if (skinny) gemm_skinny_tile(g, &bm, &bn);
+    const char* dtn = dt == DSIM_F32 ? "f32" : (dt == DSIM_F16 ? "f16" : "bf16");
+    const double e = (double)dtype_size(dt);
+    const double outc = g.epi == EPI_GEGLU ? g.N / 2 : g.N;
+    *flops = 2.0 * g.M * (double)g.N * g.K;
+    *bytes = e * ((double)g.M * (g.mode == GEMM_CONV3 ? g.C0 : g.K) + (double)g.N * g.K + (double)g.M * outc * (g.residual ? 2 : 1));
+    return std::string(skinny ? "gemm_small_" : "gemm_") + dtn + "_" + std::to_string(bm) + "x" + std::to_string(bn) +
+           (g.mode == GEMM_CONV3 ? (conv_p2 ? "_conv3p" : "_conv3") : "_linear") +
+           (g.epi == EPI_GEGLU ? "_geglu" : (g.epi == EPI_RESIDUAL ? "_res" : "")) +
+           "|M" + std::to_string(g.M) + " N" + std::to_string(g.N) + " K" + std::to_string(g.K);
+}
+
+// HIP-event bracket of one launch of a profiled forward (the executors' pbegin / pend)
+static inline void prof_begin(WeightStore* h, hipStream_t s, const std::string& name, double flops, double bytes) {
+    ProfRec r;
+    r.name = name; r.flops = flops; r.bytes = bytes;
+    (void)hipEventCreate(&r.e0);
+    (void)hipEventCreate(&r.e1);
+    (void)hipEventRecord(r.e0, s);
+    h->prof.push_back(r);
+}
+static inline void prof_end(WeightStore* h, hipStream_t s) { (void)hipEventRecord(h->prof.back().e1, s); }
+static inline int prof_get(WeightStore* h, int i, char* name, int name_cap, double* flops, double* bytes, double* ms) {
+    if (!h || i < 0 || i >= (int)h->prof.size() || !name || name_cap < 2 || !flops || !bytes || !ms) return DSIM_ERR_INVALID;
+    ProfRec& r = h->prof[i];
+    if (r.e0 && r.e1) {
+        DSIM_HIP_CHECK(hipEventSynchronize(r.e1));
+        DSIM_HIP_CHECK(hipEventElapsedTime(&r.ms, r.e0, r.e1));
+    }
+    strncpy(name, r.name.c_str(), (size_t)name_cap - 1);
+    name[name_cap - 1] = 0;
+    *flops = r.flops; *bytes = r.bytes; *ms = (double)r.ms;
+    return DSIM_OK;
+}
+
 // Repack every raw parameter into the engine's layouts.
 // ---- weight packing (finalize) ---------------------------------------------------------------
 static inline int pack_all(WeightStore* h, hipStream_t s) {

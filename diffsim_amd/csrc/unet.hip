@@ -79,23 +79,9 @@ struct Walk {
         g.zero_page = h->zero_page;
         if (!run) return DSIM_OK;
         if (h->profiling) {
-            int bm, bn;
-            gemm_launch_tile(g, h->dt, &bm, &bn);
-            const bool skinny = h->dt != DSIM_F32 && gemm_skinny_applies(g);      // the small-batch kernel (gemm_skinny.hip)
-            // 256-row 16-bit conv tiles on power-of-two output maps run the CONV3P instantiation (gemm.hip launch_typed)
-            const int hwo = g.Hout * g.Wout;
-            const bool conv_p2 = g.mode == GEMM_CONV3 && !skinny && h->dt != DSIM_F32 && bm == 256 && bn != 128 && g.Wout > 0 &&
-                                 !(g.Wout & (g.Wout - 1)) && !(hwo & (hwo - 1));
-            if (skinny) gemm_skinny_tile(g, &bm, &bn);
-            const std::string nm = std::string(skinny ? "gemm_small_" : "gemm_") + dtn() + "_" + std::to_string(bm) + "x" + std::to_string(bn) +
-                                   (g.mode == GEMM_CONV3 ? (conv_p2 ? "_conv3p" : "_conv3") : "_linear") +
-                                   (g.epi == EPI_GEGLU ? "_geglu" : (g.epi == EPI_RESIDUAL ? "_res" : ""));   // one family per kernel symbol
-            const double e = (double)es();
-            const double outc = g.epi == EPI_GEGLU ? g.N / 2 : g.N;
-            pbegin(nm + "|M" + std::to_string(g.M) + " N" + std::to_string(g.N) + " K" + std::to_string(g.K),
-                   2.0 * g.M * (double)g.N * g.K,
-                   e * ((double)g.M * (g.mode == GEMM_CONV3 ? g.C0 : g.K) + (double)g.N * g.K +
-                        (double)g.M * outc * (g.residual ? 2 : 1)));
+            double fl, by;
+            const std::string nm = gemm_family(g, h->dt, &fl, &by);
+            pbegin(nm, fl, by);
         }
         const int st = launch_gemm(g, h->dt, s);
         pend();
@@ -900,8 +886,8 @@ int dsim_op_conv3x3(const void* x, const float* w, const float* bias, const void
     CK(pack_conv3(w, DSIM_F32, wp, dtype, Cout, Cin, s));
     GemmArgs g;
     g.A0 = x; g.C0 = Cin; g.mode = GEMM_CONV3; g.Hin = H; g.Win = W;
-    g.Hout = upsample ? 2 * H : (stride == 2 ? H / 2 : H);
-    g.Wout = upsample ? 2 * W : (stride == 2 ? W / 2 : W);
+    g.Hout = upsample ? 2 * H : (stride == 2 ? (H + 1) / 2 : H);      // stride 2, padding 1: ceil(H / 2), as the executor
+    g.Wout = upsample ? 2 * W : (stride == 2 ? (W + 1) / 2 : W);
     g.stride = stride; g.ups = upsample ? 1 : 0;
     g.M = B * g.Hout * g.Wout; g.N = Cout; g.K = 9 * Cin; g.W = wp; g.bias = bias;
     g.epi = residual ? EPI_RESIDUAL : EPI_NONE; g.residual = residual; g.out = out; g.ldo = Cout; g.zero_page = zp;

@@ -70,10 +70,22 @@ struct VWalk {
     const Packed* var = h->find(key);                    \
     if (!var) return DSIM_ERR_MISSING_WEIGHT;
 
+    // per-launch HIP-event brackets of a profiled encode (dsim_vae_profile_*), same record format as the U-Net executor's
+    void pbegin(const std::string& name, double flops, double bytes) { if (run && h->profiling) prof_begin(h, s, name, flops, bytes); }
+    void pend() { if (run && h->profiling) prof_end(h, s); }
+    const char* dtn() const { return h->dt == DSIM_F32 ? "f32" : (h->dt == DSIM_F16 ? "f16" : "bf16"); }
+
     int gemm(GemmArgs& g) {
         g.zero_page = h->zero_page;
         if (!run) return DSIM_OK;
-        return launch_gemm(g, h->dt, s);
+        if (h->profiling) {
+            double fl, by;
+            const std::string nm = gemm_family(g, h->dt, &fl, &by);
+            pbegin(nm, fl, by);
+        }
+        const int st = launch_gemm(g, h->dt, s);
+        pend();
+        return st;
     }
     int linear(const void* a, int K, const void* w, const float* bias, const void* residual, void* out, int M, int N) {
         GemmArgs g;
@@ -93,8 +105,13 @@ struct VWalk {
     }
     int gn(const Act& x, const Packed* g, const Packed* b, void* out, int silu) {
         if (!run) return DSIM_OK;
-        return launch_groupnorm(x.p, x.C, nullptr, 0, (const float*)g->p, (const float*)b->p, out, n, x.H * x.W,
-                                h->cfg.norm_num_groups, 1e-6f, silu, h->dt, gn_scratch, s);
+        const int HW = x.H * x.W;
+        pbegin(std::string("groupnorm_") + dtn() + "|B" + std::to_string(n) + " HW" + std::to_string(HW) + " C" + std::to_string(x.C), 0.0,
+               (double)groupnorm_passes(x.C, 0, HW, h->cfg.norm_num_groups, h->dt) * n * HW * (double)x.C * es());
+        const int st = launch_groupnorm(x.p, x.C, nullptr, 0, (const float*)g->p, (const float*)b->p, out, n, HW,
+                                        h->cfg.norm_num_groups, 1e-6f, silu, h->dt, gn_scratch, s);
+        pend();
+        return st;
     }
 
     int resnet(const std::string& p, const Act& x, int Cout, Act* out) {
@@ -145,7 +162,12 @@ struct VWalk {
         const size_t img = (size_t)N * C * es();
         for (int i = 0; i < n; ++i) {
             CK(linear(q + i * img, C, k + i * img, nullptr, nullptr, sc, N, N));                  // S = q k^T
-            if (run) CK(launch_softmax_rows(sc, sc, N, N, 1.0f / sqrtf((float)C), h->dt, s));
+            if (run) {
+                pbegin(std::string("softmax_rows_") + dtn() + "|N" + std::to_string(N), 0.0, 2.0 * N * (double)N * es());
+                const int st = launch_softmax_rows(sc, sc, N, N, 1.0f / sqrtf((float)C), h->dt, s);
+                pend();
+                CK(st);
+            }
             CK(linear(wv->p, C, t + i * img, nullptr, nullptr, vT, C, N));                          // v^T = Wv x^T
             CK(linear(sc, N, vT, (const float*)bv->p, nullptr, o + i * img, N, C));                // O = P v + b_v
         }
@@ -160,8 +182,13 @@ struct VWalk {
         gn_scratch = ar->alloc(groupnorm_scratch_bytes(n, c.norm_num_groups));
         VGET(ciw, "encoder.conv_in.weight"); VGET(cib, "encoder.conv_in.bias");
         Act x{alloc_act((size_t)n * S * S * ch0), ch0, S, S};
-        if (run) CK(prep_conv_in(images, nullptr, 1.f, 0.f, (const float*)ciw->p, (const float*)cib->p, x.p, h->dt, n,
-                                 c.in_channels, S, ch0, 1, s));
+        if (run) {
+            pbegin("prep_conv_in", 2.0 * n * S * S * (double)ch0 * 9 * c.in_channels, (double)n * S * S * (ch0 * es() + c.in_channels * 4.0));
+            const int st = prep_conv_in(images, nullptr, 1.f, 0.f, (const float*)ciw->p, (const float*)cib->p, x.p, h->dt, n,
+                                        c.in_channels, S, ch0, 1, s);
+            pend();
+            CK(st);
+        }
         for (int i = 0; i < nl; ++i) {
             const int co = c.block_out_channels[i];
             const std::string bp = "encoder.down_blocks." + std::to_string(i) + ".";
@@ -316,6 +343,17 @@ int dsim_vae_encode(dsim_vae* h, const float* images, int n_images, int image_si
     VWalk w{h, &ar, (hipStream_t)stream, n_images, true};
     CK(w.go(images, image_size, moments));
     return ar.overflow ? DSIM_ERR_WORKSPACE : DSIM_OK;
+}
+
+int dsim_vae_profile(dsim_vae* h, int enable) {
+    if (!h) return DSIM_ERR_INVALID;
+    h->clear_profile();
+    h->profiling = enable != 0;
+    return DSIM_OK;
+}
+int dsim_vae_profile_count(const dsim_vae* h) { return h ? (int)h->prof.size() : 0; }
+int dsim_vae_profile_get(dsim_vae* h, int i, char* name, int name_cap, double* flops, double* bytes, double* ms) {
+    return prof_get(h, i, name, name_cap, flops, bytes, ms);
 }
 
 int dsim_image_preprocess(const unsigned char* pixels_hwc, float* out, int n, int H, int W, int to_half, void* stream) {

@@ -55,7 +55,7 @@ class DiffSim:
     def __init__(self, torch_dtype=torch.bfloat16, device="cuda", ip_adapter=False, *,
                  unet_config: UNetConfig = SD15, state_dict: Optional[Dict[str, torch.Tensor]] = None,
                  vae=None, encode_prompt: Optional[Callable[[str], torch.Tensor]] = None,
-                 vae_dtype=torch.float16, use_graphs: bool = False, noise_dtype=torch.float32, dedup_cfg: bool = False,
+                 vae_dtype=torch.float16, use_graphs: bool = False, noise_dtype=torch.float32, dedup_cfg: bool = True,
                  fusion: Optional[int] = None, decode_procs: Optional[int] = None):
         if ip_adapter:
             raise NotImplementedError("IP-Adapter mode is out of scope (SURVEY.md section 2 row 3)")
@@ -84,8 +84,10 @@ class DiffSim:
         self.noise_dtype = noise_dtype
         if vae is not None and hasattr(vae, "sample_dtype"):
             vae.sample_dtype = noise_dtype
-        # opt-in: conv_in, the first resnet and the first transformer's self-attention are identical in the two CFG halves
-        # (torch.cat([latents] * 2), diffsim_pipeline.py:208); compute them once per image.  Bit-identical scores, ~6 % faster.
+        # default (opt out with dedup_cfg=False): conv_in, the first resnet and the first transformer's self-attention are
+        # identical in the two CFG halves (torch.cat([latents] * 2), diffsim_pipeline.py:208); compute them once per image.
+        # Bit-identical scores (tests/test_gpu_round2.py::test_cfg_dedup_is_bit_identical), ~6 % faster.  bench.py's headline
+        # line passes dedup_cfg=False: it executes every algorithmic FLOP of the reference's duplicated batch.
         self.dedup_cfg = bool(dedup_cfg)
         self.fusion = fusion                    # None = the library default (every fused kernel); 0 = one launch per layer
         self._base: Optional[UNetEngine] = None
@@ -172,17 +174,36 @@ class DiffSim:
         nz = noise.to(self.device, torch.float32).contiguous()
         return eng.qkv(lat, nz, sa, sb, self.context(prompt))
 
+    def auto_batch_pairs(self, eng, n_pairs: int, streams: int = 2, target: int = 64) -> int:
+        """Pairs per chunk when the caller names none: `target` (the sweep's optimum on a 288 GB part), capped by the 2 GiB
+        activation bound, by the job and by the free HBM the per-stream arenas may take (half of what is free now)."""
+        bp = max(1, min(target, eng.max_images() // 2, max(1, int(n_pairs))))
+        try:
+            free, _total = torch.cuda.mem_get_info(self.device)
+        except Exception:
+            return bp
+        while bp > 1:
+            ns = max(1, min(int(streams), -(-int(n_pairs) // bp)))
+            if eng.workspace_bytes(2 * bp) * ns <= 0.5 * free:
+                break
+            bp = (bp + 1) // 2
+        return bp
+
     @torch.no_grad()
     def score_latent_pairs(self, latA, latB, noiseA, noiseB, prompt, target_block="up_blocks", target_layer=0,
-                           target_step=600, similarity="cosine", batch_pairs: int = 16, streams: int = 2) -> torch.Tensor:
+                           target_step=600, similarity="cosine", batch_pairs: Optional[int] = None, streams: int = 2) -> torch.Tensor:
         """Batched latents-in scoring: pair i = (latA[i], latB[i]) -> scores (n,) f32 on device.
         noiseA/noiseB are (1,4,s,s) (shared by every pair: each reference call reseeds) or (n,4,s,s).
         Consecutive chunks of `batch_pairs` pairs are enqueued on `streams` HIP streams in turn, so the HBM-bound kernels of
         one chunk overlap the MFMA-bound kernels of the next (same kernels, same scores).  Each stream in use owns one
-        workspace arena of the engine (streams = 2 -> two arenas, ~0.75 GB per pair of the chunk size each)."""
+        workspace arena of the engine (streams = 2 -> two arenas, ~0.75 GB per pair of the chunk size each).
+        batch_pairs=None picks the measured optimum (profiles/r04h_batch_sweep.txt: 64 pairs per chunk, 662 pairs/s against
+        603 at 16) within what fits: every activation < 2 GiB and the arenas of the streams in use inside the free HBM."""
         n = latA.shape[0]
         eng = self.engine(target_block, target_layer)
         out = torch.empty(n, dtype=torch.float32, device=self.device)
+        if batch_pairs is None:
+            batch_pairs = self.auto_batch_pairs(eng, n, streams)
         batch_pairs = max(1, min(batch_pairs, eng.max_images() // 2))      # every activation must stay < 2 GiB
         starts = list(range(0, n, batch_pairs))
         ns = max(1, min(int(streams), len(starts)))
@@ -245,9 +266,12 @@ class DiffSim:
 
     @torch.no_grad()
     def score_pairs(self, pairs: Sequence[Tuple[str, str]], img_size, prompt, target_block, target_layer, target_step,
-                    seed="2333", similarity="cosine", batch_pairs: int = 16) -> torch.Tensor:
+                    seed="2333", similarity="cosine", batch_pairs: Optional[int] = None) -> torch.Tensor:
         """Batched equivalent of calling :meth:`diffsim` once per (A, B) path pair."""
         target_layer = _norm_layer(target_layer)
+        unet_bp = batch_pairs                 # None: score_latent_pairs picks its own chunk (64 where it fits)
+        if batch_pairs is None:
+            batch_pairs = 16                  # pairs per VAE encode: 32 images at 512 px keep its widest activation < 2 GiB
         lA, lB = [], []
         nA = nB = None
         vae = self.vae
@@ -280,7 +304,7 @@ class DiffSim:
                 lA.append(latent_sample(mom, eps[0], sf, 0, 2, nd == torch.float16))
                 lB.append(latent_sample(mom, eps[1], sf, 1, 2, nd == torch.float16))
             return self.score_latent_pairs(torch.cat(lA), torch.cat(lB), nA, nB, prompt, target_block, target_layer,
-                                           target_step, similarity, batch_pairs)
+                                           target_step, similarity, unet_bp)
         for pa, pb in pairs:
             generator = get_generator(seed, "cpu")
             a = self.prepare_image_latents(process_image(load_image(pa), img_size), self.vae, None, generator)
@@ -291,4 +315,4 @@ class DiffSim:
             lA.append(a.to(self.noise_dtype).float())
             lB.append(b.to(self.noise_dtype).float())
         return self.score_latent_pairs(torch.cat(lA), torch.cat(lB), nA, nB, prompt, target_block, target_layer,
-                                       target_step, similarity, batch_pairs)
+                                       target_step, similarity, unet_bp)

@@ -364,6 +364,8 @@ def op_ff_fused(x, ln_g, ln_b, w1, b1, w2, b2, eps=1e-5):
     """x + ff.net.2(GEGLU(ff.net.0.proj(LayerNorm(x)))) in one launch (bf16, C = 320); w1 [8C][C], w2 [C][4C] f32."""
     L = _lib.lib()
     _require_cuda(x, ln_g, ln_b, w1, b1, w2, b2)
+    if x.dtype != torch.bfloat16:          # the op-level entry point packs and launches in bf16 only (the engines run the fp16 twin)
+        raise TypeError("op_ff_fused takes a torch.bfloat16 input")
     M, Cc = x.shape
     out = torch.empty_like(x)
     _lib.check(L.dsim_op_ff_fused(x.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
@@ -376,6 +378,8 @@ def op_ln_linear(x, ln_g, ln_b, w, eps=1e-5):
     skips the LayerNorm."""
     L = _lib.lib()
     _require_cuda(x, ln_g, ln_b, w)
+    if x.dtype != torch.bfloat16:          # as op_ff_fused: bf16 only at the op level
+        raise TypeError("op_ln_linear takes a torch.bfloat16 input")
     M, Cc = x.shape
     N = w.shape[0]
     out = torch.empty((M, N), dtype=x.dtype, device=x.device)
@@ -390,7 +394,7 @@ def op_conv3x3(x, w, bias=None, residual=None, stride=1, upsample=False):
     _require_cuda(x, w, bias, residual)
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
-    Ho, Wo = (2 * H, 2 * W) if upsample else ((H // 2, W // 2) if stride == 2 else (H, W))
+    Ho, Wo = (2 * H, 2 * W) if upsample else (((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W))      # ceil: odd sides (as the executor)
     out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
     _lib.check(L.dsim_op_conv3x3(x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), out.data_ptr(), B, H, W, Cin,
                                  Cout, stride, int(upsample), _TORCH2DSIM[x.dtype], _stream_ptr()), "op_conv3x3")
@@ -585,6 +589,22 @@ class VAEEncoder:
 
     def encode(self, images: torch.Tensor) -> _EncodeOut:
         return _EncodeOut(self.moments(images), self.sample_dtype)
+
+    def profile(self, enable: bool):
+        """HIP-event brackets around every launch of the following encodes (dsim_vae_profile); not inside a timed region."""
+        _lib.check(self.L.dsim_vae_profile(self._h, int(enable)), "vae profile")
+
+    def profile_records(self, detail: bool = False):
+        """Same records as UNetEngine.profile_records."""
+        torch.cuda.synchronize(self.device)
+        out = []
+        buf = C.create_string_buffer(160)
+        fl, by, ms = C.c_double(), C.c_double(), C.c_double()
+        for i in range(self.L.dsim_vae_profile_count(self._h)):
+            _lib.check(self.L.dsim_vae_profile_get(self._h, i, buf, 160, C.byref(fl), C.byref(by), C.byref(ms)), "vae profile_get")
+            fam, _, shape = buf.value.decode().partition("|")
+            out.append((fam, fl.value, by.value, ms.value, shape) if detail else (fam, fl.value, by.value, ms.value))
+        return out
 
 
 # ---- DiT backbone (SURVEY.md section 8a row a11) ---------------------------------------------------------

@@ -30,10 +30,11 @@ from .parallel import gather_scores, shard_triplets
 @torch.no_grad()
 def score_latent_triplets(scorer, lat_ref: torch.Tensor, lat_left: torch.Tensor, lat_right: torch.Tensor,
                           noiseA: torch.Tensor, noiseB: torch.Tensor, prompt, target_block="up_blocks", target_layer=0,
-                          target_step=600, similarity="cosine", batch_triplets: int = 10, return_status: bool = False):
+                          target_step=600, similarity="cosine", batch_triplets: Optional[int] = None, return_status: bool = False):
     """Scores (ref,left) and (ref,right) for every triplet; ref sits in slot A (noiseA), left and
     right in slot B (noiseB) exactly as two reference calls would place them.  Returns two (n,) f32
-    device tensors that are bit-identical to 2n separate ``diffsim_latents`` calls (any scorer kind)."""
+    device tensors that are bit-identical to 2n separate ``diffsim_latents`` calls (any scorer kind).
+    batch_triplets=None: the engine batch of the measured optimum (``_Adapter.auto_triplets``)."""
     s_l, s_r, bad = _score_chunks(_Adapter(scorer), lat_ref, lat_left, lat_right, noiseA, noiseB, prompt, target_block,
                                   target_layer, target_step, similarity, batch_triplets)
     return (s_l, s_r, bad) if return_status else (s_l, s_r)
@@ -107,6 +108,27 @@ class _Adapter:
             return self.s.engine(int(layer[0])).heads
         return self.s.engine(block, layer if self.kind == "xl" else _norm_layer(layer)).heads
 
+    def engine(self, block, layer):
+        if self.kind == "dit":
+            return self.s.engine(int(layer[0]))
+        return self.s.engine(block, layer if self.kind == "xl" else _norm_layer(layer))
+
+    def auto_triplets(self, block, layer, n: int) -> int:
+        """Triplets per engine batch when the caller names none: the image count of the batch sweeps' optimum (SD1.5 and
+        DiT: 128 images = 64 pairs, profiles/r04h_batch_sweep.txt; SDXL at 1024 px: 16), inside the 2 GiB activation bound
+        and half of the free HBM."""
+        eng = self.engine(block, layer)
+        t = max(1, min((16 if self.kind == "xl" else 128) // 3, max(1, int(n))))
+        if hasattr(eng, "max_images"):
+            t = max(1, min(t, eng.max_images() // 3))
+        try:
+            free, _total = torch.cuda.mem_get_info(self.s.device)
+            while t > 1 and hasattr(eng, "workspace_bytes") and eng.workspace_bytes(3 * t) > 0.5 * free:
+                t = (t + 1) // 2
+        except Exception:
+            pass
+        return t
+
     def features(self, lat, nz, prompt, block, layer, step):
         if self.kind == "sd15":
             return self.s.features(lat, nz, prompt, block, _norm_layer(layer), step)
@@ -131,6 +153,8 @@ def _score_chunks(ad: _Adapter, ref, left, right, nA, nB, prompt, block, layer, 
     bad = torch.zeros((), dtype=torch.int32, device=dev)
     shp = ref.shape[1:]
     heads = ad.heads(block, layer)
+    if batch_triplets is None:
+        batch_triplets = ad.auto_triplets(block, layer, n)
     for i0 in range(0, n, batch_triplets):
         i1 = min(n, i0 + batch_triplets)
         m = i1 - i0
@@ -146,7 +170,8 @@ def _score_chunks(ad: _Adapter, ref, left, right, nA, nB, prompt, block, layer, 
 
 @torch.no_grad()
 def score_path_triplets(scorer, triplets: Sequence[Tuple[str, str, str, str]], img_size: int, target_block, target_layer,
-                        target_step, seed=2333, similarity="cosine", rank: int = 0, world: int = 1, batch_triplets: int = 10):
+                        target_step, seed=2333, similarity="cosine", rank: int = 0, world: int = 1, batch_triplets: int = 10,
+                        unet_triplets: Optional[int] = None):
     """Scores s(A,B) and s(A,C) of every (A, B, C, prompt) path triplet -- the two scorer calls per triplet the
     reference's loops make (cute_main.py:111-132, night_main.py:69-90, style_main.py:150-175) -- for all three scorer
     kinds (DiffSim, diffsim_xl, diffsim_DiT): whole triplets sharded over ranks (the cached reference-image features stay
@@ -212,8 +237,9 @@ def score_path_triplets(scorer, triplets: Sequence[Tuple[str, str, str, str]], i
                 _prepare(scorer, ad, process_image(load_image(pa), img_size), g2)
                 c = _prepare(scorer, ad, process_image(load_image(pc), img_size), g2)
                 ref.append(a); left.append(b); right.append(c)
+        # (batch_triplets sizes the decode / VAE-encode chunks above; the U-Net batch is chosen by the adapter)
         a_, b_, bad = _score_chunks(ad, torch.cat(ref), torch.cat(left), torch.cat(right), draws[2], draws[3], prompt,
-                                    target_block, target_layer, target_step, similarity, batch_triplets)
+                                    target_block, target_layer, target_step, similarity, unet_triplets)
         nbad += bad
         sl.append(a_); sr.append(b_); order += idxs
     if order:

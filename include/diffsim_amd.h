@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DSIM_ABI_VERSION 6
+#define DSIM_ABI_VERSION 7
 
 typedef enum dsim_status {
     DSIM_OK = 0,
@@ -214,6 +214,11 @@ size_t dsim_vae_workspace_bytes(const dsim_vae* h, int n_images, int image_size)
  * = cat(mean, logvar) exactly as AutoencoderKL's quant_conv output */
 int    dsim_vae_encode(dsim_vae* h, const float* images, int n_images, int image_size, float* moments,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* Measurement aid (ABI v7), same contract and record format as dsim_unet_profile / _count / _get: per launch of the next
+ * dsim_vae_encode calls, the kernel family, its algorithmic FLOPs / bytes and its HIP-event duration on the launch stream */
+int    dsim_vae_profile(dsim_vae* h, int enable);
+int    dsim_vae_profile_count(const dsim_vae* h);
+int    dsim_vae_profile_get(dsim_vae* h, int i, char* name, int name_cap, double* flops, double* bytes, double* ms);
 
 /* ---- DiT-XL/2 scorer backbone: replaces `diffusion.p_sample(model, latents, t,
  *      model_kwargs=dict(y=[1, 1000]))` + the pre-hook on model.blocks[L].attn of diffsim/diffsim_dit.py:93-114.

@@ -79,7 +79,8 @@ def test_linear_geglu(eng, dtype, M, C):
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [
     (2, 16, 16, 64, 128, 1, False), (3, 8, 8, 320, 320, 1, False), (2, 16, 16, 128, 128, 2, False),
     (2, 8, 8, 128, 64, 1, True), (1, 5, 7, 64, 160, 1, False), (2, 32, 32, 320, 320, 1, False),
-    (2, 8, 8, 1920, 1280, 1, False), (2, 6, 6, 64, 64, 2, False)])
+    (2, 8, 8, 1920, 1280, 1, False), (2, 6, 6, 64, 64, 2, False),
+    (2, 7, 7, 64, 128, 2, False), (1, 9, 5, 128, 64, 2, False)])          # odd sides through stride 2: ceil(H / 2) rows (--image_size 224)
 def test_conv3x3(eng, dtype, B, H, W, Cin, Cout, stride, ups):
     g = torch.Generator().manual_seed(B * 1000 + H + Cin + Cout + stride)
     x = torch.randn(B, Cin, H, W, generator=g)

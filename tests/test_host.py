@@ -29,7 +29,7 @@ def test_abi_exports_every_declared_symbol(lib):
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.dsim_version() == 6
+    assert lib.dsim_version() == 7
     assert lib.dsim_strerror(0) == b"ok"
     assert b"workspace" in lib.dsim_strerror(-3)
 

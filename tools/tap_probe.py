@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """The tap layer alone, for rocprofv3 --pmc passes (north_star: MFMA utilisation on the up_blocks[0] attention GEMM):
-the tapped to_q | to_k | to_v projection at the bench batch as the ONE launch the engine makes of it (65536 x 3840 x 1280, bf16:
-DSIM_FUSE_TAPQKV; up to round 3 three 1280-column launches) and the fused score tail (4 x SDPA of 256 tokens x 8 heads x 160
+the tapped to_q | to_k | to_v projection at the bench batch as ONE 65536 x 3840 x 1280 bf16 launch through op_linear (the same
+gemm_kernel instantiation, tile walk and K loop as the engine's DSIM_FUSE_TAPQKV launch; the engine's launch additionally
+splits its output columns over three tensors in the epilogue -- GemmArgs.out_split, a per-tile store-descriptor select -- which
+op_linear does not exercise; up to round 3 the engine made three 1280-column launches) and the fused score tail (4 x SDPA of 256 tokens x 8 heads x 160
 + cosine) for 64 pairs.  tools/profile_round.sh runs it under the counters and
 profiles/summarize_tap.py turns the csv into profiles/<tag>_tap_pmc.json."""
 import os

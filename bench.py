@@ -433,8 +433,12 @@ def headline(a, world, rank, dev):
     cfg = C.SD15
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(a.dtype, torch.float32)
     keys = [k for k in C.unet_param_shapes(cfg) if not k.startswith(TAP_KEYS_EXCLUDE)]
-    sd = S.make_state_dict(cfg, seed=0, keys=keys)
+    sd = S.make_state_dict_shared(cfg, seed=0, keys=keys, rank=rank, world=world)      # rank 0 synthesises, the others map its file
     ds = DiffSim(torch_dtype=dtype, device=str(dev), unet_config=cfg, state_dict=sd, dedup_cfg=a.dedup_cfg, fusion=a.fusion)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()                     # every rank has mapped rank 0's weight file
+        S.cleanup_shared()
     eng = ds.engine("up_blocks", 0)
     t = sched.timestep_from_index(600)
     eng.set_timestep(t)
@@ -461,7 +465,11 @@ def headline(a, world, rank, dev):
     if a.pixels_in:
         from diffsim_amd.engine import VAEEncoder
         vae = VAEEncoder(C.VAE_SD15, S.make_state_dict(C.VAE_SD15, seed=1), dtype, str(dev))
-        imgs = torch.cat([torch.cat(S.make_image_pair(rank * bp + i, 512)) for i in range(bp)]).to(dev)   # [2*bp,3,512,512]
+        # bp pairs of synthetic 512 x 512 images resident in HBM (the generator is slow on the host: at most 16 distinct pairs, tiled);
+        # VAEEncoder.moments encodes them in chunks that keep its widest activation < 2 GiB, the U-Net then runs ONE bp-pair batch
+        nd = min(bp, 16)
+        base = torch.cat([torch.cat(S.make_image_pair(rank * nd + i, 512)) for i in range(nd)])
+        imgs = base.repeat((bp + nd - 1) // nd, 1, 1, 1)[:2 * bp].to(dev)          # [2*bp,3,512,512]
         eps = torch.cat([noise[0], noise[1]] * bp).to(dev).contiguous()         # the two VAE-sample draws (reference order)
         from diffsim_amd.engine import latent_sample
 
@@ -577,7 +585,7 @@ def main():
                     help="CPU-only check of the N-rank launch + gloo plumbing (no kernels, no throughput)")
     a = ap.parse_args()
     if a.batch_pairs is None:
-        a.batch_pairs = {"sd15": 16 if a.pixels_in else 64, "sdxl": 8, "dit": 64}[a.model]
+        a.batch_pairs = {"sd15": 64, "sdxl": 8, "dit": 64}[a.model]
 
     # ---- N ranks: either a torch.distributed launcher started us (WORLD_SIZE set), or we start them ourselves -----
     if a.gpus < 1:

@@ -58,6 +58,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--fp8_attention", action="store_true", help="--metric dit: e4m3 MFMA attention")
     p.add_argument("--dedup_cfg", dest="dedup_cfg", action="store_true", default=True,
                    help="--metric diffsim: compute what the two CFG halves share once per image (bit-identical scores, ~6 %% faster); the default")
+    p.add_argument("--selftest_shard", action="store_true",
+                   help="CPU-only check of the N-rank triplet sharding: the dataset walk, the strided shard, the two score gathers and "
+                        "the printed counts over gloo with a stand-in scorer (no GPU, no weights)")
     p.add_argument("--no_dedup_cfg", dest="dedup_cfg", action="store_false",
                    help="--metric diffsim: run the reference's duplicated CFG batch through every layer")
     return p
@@ -159,11 +162,33 @@ def build_scorer(args):
     return loader.load_diffsim_dit(args.model_path, args.image_size, args.target_step, args.dtype, dev, args.fp8_attention)
 
 
+def _selftest_scores(trip, rank, world):
+    """Stand-in for harness.score_path_triplets on CPU (--selftest_shard): every rank scores ITS strided shard of the triplets with
+    a deterministic function of the file names, then the same two gathers as the real path.  DSIM_SELFTEST_DIE_RANK=r makes
+    rank r exit 9 between the two collectives (the supervising launcher must stop the others, which are then waiting in the second)."""
+    import torch
+    from . import parallel as P
+
+    def fake(a, b):
+        return ((sum(map(ord, os.path.basename(a))) * 31 + sum(map(ord, os.path.basename(b))) * 17) % 997) / 997.0
+    mine = P.shard_triplets(len(trip), rank, world)
+    loc_ab = torch.tensor([fake(trip[j][0], trip[j][1]) for j in mine], dtype=torch.float32)
+    loc_ac = torch.tensor([fake(trip[j][0], trip[j][2]) for j in mine], dtype=torch.float32)
+    s_ab = P.gather_scores(loc_ab, len(trip), rank, world)
+    if os.environ.get("DSIM_SELFTEST_DIE_RANK") == str(rank):
+        sys.exit(9)
+    s_ac = P.gather_scores(loc_ac, len(trip), rank, world)
+    return s_ab, s_ac, 0
+
+
 def run(args) -> int:
     import torch
     from . import harness as H
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    if world > 1 and args.selftest_shard:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    elif world > 1:
         import torch.distributed as dist
         from .parallel import pin_to_gpu_numa
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -171,7 +196,7 @@ def run(args) -> int:
         pin_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")))       # image decode threads next to this rank's GPU
         dist.init_process_group("nccl")
     os.environ.setdefault("DSIM_DECODE_PROCS", str(args.decode_procs))      # the scorers' DecodePool default
-    scorer = build_scorer(args)
+    scorer = None if args.selftest_shard else build_scorer(args)
     layer = args.target_layer if isinstance(args.target_layer, list) else [args.target_layer]
     if rank == 0:
         print(f"=========seed {args.seed}=========")
@@ -183,8 +208,11 @@ def run(args) -> int:
         trip = sref_triplets(args.image_path, args.seed, args.prompt, args.experiments)
     else:
         trip = cute_triplets(args.image_path, args.seed)
-    s_ab, s_ac, bad = H.score_path_triplets(scorer, trip, args.image_size, args.target_block, layer, args.target_step, args.seed,
-                                            args.similarity, rank, world, args.batch)
+    if args.selftest_shard:
+        s_ab, s_ac, bad = _selftest_scores(trip, rank, world)
+    else:
+        s_ab, s_ac, bad = H.score_path_triplets(scorer, trip, args.image_size, args.target_block, layer, args.target_step, args.seed,
+                                                args.similarity, rank, world, args.batch)
     if rank == 0:
         total = len(trip)
         if bad:

@@ -57,6 +57,54 @@ def make_state_dict(cfg: UNetConfig, seed: int = 0, keys: Optional[Sequence[str]
     return out
 
 
+_SHARED_FILES = []          # files this process (rank 0) wrote for the other ranks
+
+
+def cleanup_shared():
+    """Rank 0, once every rank has loaded (after a barrier): remove the shared files (they sit in /dev/shm, i.e. in memory)."""
+    import os
+    while _SHARED_FILES:
+        try:
+            os.remove(_SHARED_FILES.pop())
+        except OSError:
+            pass
+
+
+def make_state_dict_shared(cfg, seed: int = 0, keys: Optional[Sequence[str]] = None, rank: int = 0, world: int = 1,
+                           cache_dir: Optional[str] = None, timeout_s: float = 900.0) -> Dict[str, torch.Tensor]:
+    """``make_state_dict`` for the N ranks of ONE node: rank 0 synthesises the tensors (698 M parameters for SD1.5 to the tap:
+    tens of seconds of host time) and writes them once as a safetensors file under `cache_dir` (default: /dev/shm or the temp
+    directory); the other ranks wait for the file and map it instead of each repeating the synthesis on the same cores.  File
+    based, so it works before any process group exists; the name carries the config, seed and key set, and the file appears
+    atomically (written under a temporary name, then renamed).  Same tensors as make_state_dict, bit for bit."""
+    if world <= 1:
+        return make_state_dict(cfg, seed, keys)
+    import hashlib
+    import os
+    import tempfile
+    import time
+    from safetensors.torch import load_file, save_file
+    d = cache_dir or ("/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir())
+    # (MASTER_PORT: one file per launch, never a stale one of an earlier run of other code)
+    tag = hashlib.sha256((repr(cfg) + "|" + str(seed) + "|" + os.environ.get("MASTER_PORT", "") + "|" +
+                          ",".join(sorted(keys) if keys is not None else ["*"])).encode()).hexdigest()[:16]
+    path = os.path.join(d, f"dsim_synth_{os.getuid()}_{tag}.safetensors")
+    if rank == 0:
+        sd = make_state_dict(cfg, seed, keys)
+        if not os.path.exists(path):
+            tmp = f"{path}.{os.getpid()}.tmp"
+            save_file(sd, tmp)
+            os.replace(tmp, path)
+        _SHARED_FILES.append(path)
+        return sd
+    t0 = time.monotonic()
+    while not os.path.exists(path):
+        if time.monotonic() - t0 > timeout_s:
+            raise TimeoutError(f"rank {rank}: {path} did not appear within {timeout_s:.0f} s (did rank 0 fail?)")
+        time.sleep(0.2)
+    return load_file(path)
+
+
 def add_checkpoint_like_outliers(sd: Dict[str, torch.Tensor], seed: int = 5, conv_gain: float = 40.0, qk_gain: float = 5.0
                                  ) -> Dict[str, torch.Tensor]:
     """What trained checkpoints have and `make_state_dict` does not: (1) a few OUTLIER CHANNELS -- three output channels of

@@ -104,3 +104,51 @@ def test_spawn_ranks_forwards_sigterm(tmp_path):
     p.send_signal(signal.SIGTERM)
     rc = p.wait(timeout=30)
     assert rc == 128 + signal.SIGTERM
+
+
+def test_self_launch_eight_ranks():
+    """The driver's scaling run goes to 8 ranks: the same plumbing at the full node width (gloo on CPU)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--selftest-launch"],
+                       capture_output=True, text=True, env=_env(), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 8 and d["n_ranks_seen"] == 8 and d["ranks_in_gather"] == list(range(8))
+    assert abs(d["max_rank_s"] - 8e-3) < 1e-9          # MAX over ranks: rank 7 reports 8 ms
+
+
+def _cute_tree(root, n_cls=2, n_inst=3, n_light=2, n_img=3):
+    from PIL import Image
+    for c in range(n_cls):
+        for i in range(n_inst):
+            for l in range(n_light):
+                d = os.path.join(root, f"cls{c}", f"inst{i}", f"light{l}")
+                os.makedirs(d)
+                for k in range(n_img):
+                    Image.new("RGB", (8, 8), (c * 40, i * 40, k * 40)).save(os.path.join(d, f"im{k}.png"))
+
+
+def test_cli_triplet_shard_eight_ranks(tmp_path):
+    """python -m diffsim_amd --ngpu 8: the CUTE walk sharded over 8 ranks (60 triplets: shards of 8 and 7), both score gathers and
+    the printed counts must equal the 1-rank run (stand-in scorer on CPU, gloo)."""
+    _cute_tree(str(tmp_path))
+    base = [sys.executable, "-m", "diffsim_amd", "--image_path", str(tmp_path), "--target_layer", "0", "--target_step", "600",
+            "--similarity", "cosine", "--seed", "2334", "--selftest_shard"]
+    r1 = subprocess.run(base, capture_output=True, text=True, env=_env(), cwd=ROOT, timeout=300)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r8 = subprocess.run(base + ["--ngpu", "8"], capture_output=True, text=True, env=_env(), cwd=ROOT, timeout=600)
+    assert r8.returncode == 0, r8.stderr[-2000:]
+    keep = lambda out: [ln for ln in out.splitlines() if ln.startswith(("Total", "Accuracy", "2x", "Final"))]
+    assert keep(r1.stdout) and keep(r1.stdout) == keep(r8.stdout)
+
+
+def test_cli_rank_dying_between_the_collectives_stops_the_launch(tmp_path):
+    """Rank 5 of 8 exits between the two score gathers; the other seven are then waiting in the second all_gather.  The
+    supervising launcher must stop them and return the failing code within seconds, not at the collective's timeout."""
+    import time
+    _cute_tree(str(tmp_path))
+    cmd = [sys.executable, "-m", "diffsim_amd", "--image_path", str(tmp_path), "--target_layer", "0", "--target_step", "600",
+           "--similarity", "cosine", "--selftest_shard", "--ngpu", "8"]
+    t0 = time.monotonic()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(_env(), DSIM_SELFTEST_DIE_RANK="5"), cwd=ROOT, timeout=600)
+    assert r.returncode == 9, (r.returncode, r.stderr[-2000:])
+    assert time.monotonic() - t0 < 180 and "stopping the other ranks" in r.stderr

@@ -261,3 +261,20 @@ def test_decode_pool_processes_match_the_in_process_path(tmp_path):
                 DecodePool.gather(pool.submit([str(tmp_path / "missing.png")], 32))
             assert torch.equal(DecodePool.gather(pool.submit(paths[:2], 32)), want[:2])       # the workers survive a failure
         pool.shutdown()
+
+
+def test_shared_synthetic_weights_are_written_once_and_mapped(tmp_path):
+    """bench.py's N-rank runs: rank 0 writes the synthetic state dict once, the other ranks map that file -- same tensors bit for
+    bit, and a rank whose file never appears fails with a message instead of hanging."""
+    import torch
+    from diffsim_amd import config as C, synth as S
+    keys = [k for k in C.unet_param_shapes(C.TINY) if k.startswith(("conv_in", "down_blocks.0"))]
+    a = S.make_state_dict_shared(C.TINY, 3, keys, rank=0, world=8, cache_dir=str(tmp_path))
+    files = list(tmp_path.iterdir())
+    assert len(files) == 1 and files[0].suffix == ".safetensors"
+    b = S.make_state_dict_shared(C.TINY, 3, keys, rank=5, world=8, cache_dir=str(tmp_path))
+    ref = S.make_state_dict(C.TINY, 3, keys)
+    assert set(a) == set(b) == set(ref) and all(torch.equal(a[k], ref[k]) and torch.equal(b[k], ref[k]) for k in ref)
+    import pytest
+    with pytest.raises(TimeoutError):
+        S.make_state_dict_shared(C.TINY, 4, keys, rank=1, world=8, cache_dir=str(tmp_path), timeout_s=0.5)

@@ -71,6 +71,25 @@ def test_sharded_scores_match_single_process(n):
     assert sorted(seen) == list(range(n))          # every pair scored exactly once
 
 
+def test_sharded_scores_match_single_process_world8():
+    """The node's full width: 8 ranks, 13 pairs (shards of 2 and 1) -- every pair scored exactly once, gathered in order."""
+    world, port, n = 8, _free_port(), 13
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    seen = []
+    for rank, ok, idx in res:
+        assert ok, f"rank {rank} gathered scores differ from the single-process run"
+        seen += idx
+    assert sorted(seen) == list(range(n))
+
+
 def test_shard_balance():
     for n in (0, 1, 9, 10000):
         for w in (1, 2, 4, 8):

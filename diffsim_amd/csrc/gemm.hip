@@ -119,7 +119,9 @@ void gemm_launch_tile(const GemmArgs& a, int dtype, int* bm, int* bn) {
     bool big = *bm == 256 && dtype != DSIM_F32;
     if (big && slow && *bn == 320 && !act_only) big = false;
     if (!big) {
-        const bool n160 = *bn == 160 || (a.epi == EPI_GEGLU && a.geglu_blk == 16);
+        // (a 320-column choice the f32 mode cannot run falls back to 160 columns, not 128: N % 320 == 0 there, and the one-launch
+        //  tapped q | k | v needs the tile width to divide out_split, a multiple of 320)
+        const bool n160 = *bn == 160 || (*bn == 320 && !slow) || (a.epi == EPI_GEGLU && a.geglu_blk == 16);
         const bool n80 = *bn == 80 && dtype != DSIM_F32 && !slow;          // (16-bit instantiations only; f32: the 160-column tile)
         *bm = 128;
         *bn = slow ? 128 : (n80 ? 80 : ((n160 || *bn == 80) ? 160 : 128));

@@ -188,3 +188,121 @@ def test_nights_shaped_triplets_full_size():
         assert abs(got - want) <= 5e-3, (got, want)
     assert H.nights_decisions(bl.cpu(), br.cpu(), "cosine").tolist() == \
         H.nights_decisions(torch.tensor(want_l), torch.tensor(want_r), "cosine").tolist()
+
+
+def test_sd15_full_size_ragged_side_28():
+    """--image_size 224: the FULL-size SD1.5 graph at latent side 28 (28 -> 14 -> 7 -> 4), where the kernel families the tiny
+    config never reaches run on odd maps: ff_fused / rowlin with M % 128 != 0, one-pass GroupNorm at HW = 49 and 16 with
+    C = 1280, attn_short / attn_kernel with ragged query counts (784, 196, 49), gemm_skinny and 128 x 80 convs on
+    non-power-of-two maps, the CONV3 instantiation instead of CONV3P, resize_nearest at C = 1280 (4 -> 7: the tap
+    ("up_blocks", 0) sits behind that explicit-size upsample).  fp32 kernel mode against the oracle at 1e-4 for one pair per
+    call (small-batch kernels) and inside a batch of 32 pairs (regular tiles); bf16 / fp16 within their bounds, and rows of the
+    1-pair call bit-equal to the same pair inside the 32-pair batch."""
+    from oracle import cpu_ref as R
+    from diffsim_amd.diffsim import DiffSim
+    cfg = C.SD15
+    shapes = C.unet_param_shapes(cfg)
+    sd = S.make_state_dict(cfg, seed=0, keys=[k for k in shapes if not k.startswith(("conv_norm_out", "conv_out"))])
+    unet = _oracle_unet(R, R.SD15, sd, shapes)
+    ctx = S.make_context(cfg)
+    side, npairs = 28, 32
+    g = torch.Generator("cpu").manual_seed(2800)
+    zA, zB = (0.18215 * 4.0 * torch.randn((npairs, 4, side, side), generator=g) for _ in range(2))
+    nA, nB = (torch.randn((1, 4, side, side), generator=g) for _ in range(2))
+    taps = (("up_blocks", 0), ("up_blocks", 2), ("down_blocks", 1), ("mid_blocks", 0))
+    probe = (0, 31)                                  # pairs checked against the oracle
+    want = {(t, i): float(R.diffsim_latents(unet, zA[i:i + 1], zB[i:i + 1], nA, nB, ctx, 600, t[0], t[1], "cosine"))
+            for t in taps for i in probe}
+    del unet
+    ds = DiffSim(torch_dtype=torch.float32, device="cuda", unet_config=cfg, state_dict=sd)
+    for t in taps:
+        one = float(ds.diffsim_latents(zA[:1], zB[:1], nA, nB, ctx, t[0], t[1], 600, "cosine").cpu())
+        assert _rel(one, want[(t, 0)]) <= REL_F32, (t, one, want[(t, 0)])
+        allp = ds.score_latent_pairs(zA, zB, nA, nB, ctx, t[0], t[1], 600, "cosine", batch_pairs=npairs).cpu()
+        for i in probe:
+            assert _rel(float(allp[i]), want[(t, i)]) <= REL_F32, (t, i, float(allp[i]), want[(t, i)])
+    eng = ds.engine("up_blocks", 0)
+    assert eng.tokens == 7 * 7                       # behind the 4 -> 7 explicit-size upsample
+    del ds
+    torch.cuda.empty_cache()
+    for dtype, bound in ((torch.bfloat16, 5e-3), (torch.float16, 1e-3)):
+        d16 = DiffSim(torch_dtype=dtype, device="cuda", unet_config=cfg, state_dict=sd)
+        for t in taps:
+            allp = d16.score_latent_pairs(zA, zB, nA, nB, ctx, t[0], t[1], 600, "cosine", batch_pairs=npairs).cpu()
+            one = d16.score_latent_pairs(zA[:1], zB[:1], nA, nB, ctx, t[0], t[1], 600, "cosine").cpu()
+            assert torch.equal(one[0], allp[0]), (dtype, t)          # small-batch kernels == regular tiles, bit for bit
+            for i in probe:
+                assert abs(float(allp[i]) - want[(t, i)]) <= bound, (dtype, t, i, float(allp[i]), want[(t, i)])
+        del d16
+        torch.cuda.empty_cache()
+
+
+def test_sdxl_ragged_side_26():
+    """The SDXL graph at latent side 26 (--image_size 208: 26 -> 13 -> 7; the reference accepts any --image_size and keeps its
+    native-size time ids): fp32 kernel mode against the oracle (U-Net in fp32, the final cosine in float64 as in
+    test_sdxl_1024px_two_taps) at 1e-4 for the depth-10 level at 7 x 7, a tap at 13 x 13 behind the explicit-size 7 -> 13
+    upsample and one on the down path, one pair and a batch of 8; bf16 / fp16 within their bounds."""
+    from oracle import cpu_ref as R
+    from diffsim_amd.diffsim_xl import diffsim_xl
+    cfg = C.SDXL
+    drop = ("up_blocks.2", "conv_norm_out", "conv_out")
+    shapes = C.unet_param_shapes(cfg)
+    sd = S.make_state_dict(cfg, seed=0, keys=[k for k in shapes if not k.startswith(drop)])
+    unet = _oracle_unet(R, R.SDXL, sd, shapes, torch.float32)
+    ctx, pooled = S.make_context(cfg), S.make_pooled(cfg)
+    side, npairs = 26, 8
+    g = torch.Generator("cpu").manual_seed(2801)
+    zA, zB = (torch.randn((npairs, 4, side, side), generator=g) for _ in range(2))
+    nA, nB = (torch.randn((1, 4, side, side), generator=g) for _ in range(2))
+    taps = (("up_blocks", [0, 0, 0]), ("up_blocks", [1, 2, 1]), ("down_blocks", [1, 1, 0]))
+    f64 = torch.float64
+    want = {}
+    for ti, (blk, tl) in enumerate(taps):
+        for i in (0, npairs - 1):
+            fa = R.features_xl(unet, zA[i:i + 1], nA, ctx, pooled, 600, blk, tl)
+            fb = R.features_xl(unet, zB[i:i + 1], nB, ctx, pooled, 600, blk, tl)
+            want[(ti, i)] = float(R.pair_score(*[f.to(f64) for f in fa], *[f.to(f64) for f in fb], "cosine"))
+    del unet
+    xl = diffsim_xl(torch.float32, "cuda", unet_config=cfg, state_dict=sd)
+    for ti, (blk, tl) in enumerate(taps):
+        one = float(xl.score_latent_pairs(zA[:1], zB[:1], nA, nB, ctx, pooled, blk, tl, 600, "cosine").cpu())
+        assert _rel(one, want[(ti, 0)]) <= REL_F32, (blk, tl, one, want[(ti, 0)])
+        allp = xl.score_latent_pairs(zA, zB, nA, nB, ctx, pooled, blk, tl, 600, "cosine", batch_pairs=npairs).cpu()
+        for i in (0, npairs - 1):
+            assert _rel(float(allp[i]), want[(ti, i)]) <= REL_F32, (blk, tl, i, float(allp[i]), want[(ti, i)])
+    del xl
+    torch.cuda.empty_cache()
+    for dtype, bound in ((torch.bfloat16, 1e-2), (torch.float16, 2e-3)):
+        x16 = diffsim_xl(dtype, "cuda", unet_config=cfg, state_dict=sd)
+        for ti, (blk, tl) in enumerate(taps):
+            allp = x16.score_latent_pairs(zA, zB, nA, nB, ctx, pooled, blk, tl, 600, "cosine", batch_pairs=npairs).cpu()
+            for i in (0, npairs - 1):
+                assert abs(float(allp[i]) - want[(ti, i)]) <= bound, (dtype, blk, tl, i, float(allp[i]), want[(ti, i)])
+        del x16
+        torch.cuda.empty_cache()
+
+
+def test_fp32_tap_at_the_320_channel_level_with_many_rows():
+    """Regression (round 5): the one-launch tapped q | k | v projection (GemmArgs.out_split) needs a tile width that divides the
+    split.  In the f32 parity mode an N % 320 == 0 problem with >= 256 big tiles (3 or more images at 64 x 64, taps
+    ("down_blocks", 0) / ("up_blocks", 2)) used to fall back to 128-column tiles, whose third tile straddles the q | k boundary at
+    column 320 and wrote part of k into q's tensor; the full-size fp32 tests only tapped the 1280-channel level.  Two pairs
+    (8 U-Net batch elements, 32768 rows) against the oracle at 1e-4, and the same pairs one per call."""
+    from oracle import cpu_ref as R
+    from diffsim_amd.diffsim import DiffSim
+    cfg = C.SD15
+    shapes = C.unet_param_shapes(cfg)
+    sd = S.make_state_dict(cfg, seed=0, keys=[k for k in shapes if k.startswith(("conv_in", "time_embedding", "down_blocks.0"))])
+    unet = _oracle_unet(R, R.SD15, sd, shapes)
+    ctx = S.make_context(cfg)
+    lat = [S.make_pair_latents(cfg, i) for i in range(2)]
+    zA, zB = torch.cat([p[0] for p in lat]), torch.cat([p[1] for p in lat])
+    n = S.draw_pair_noise(2334, lat[0][0].shape)
+    want = [float(R.diffsim_latents(unet, zA[i:i + 1], zB[i:i + 1], n[2], n[3], ctx, 600, "down_blocks", 0, "cosine")) for i in range(2)]
+    del unet
+    ds = DiffSim(torch_dtype=torch.float32, device="cuda", unet_config=cfg, state_dict=sd)
+    both = ds.score_latent_pairs(zA, zB, n[2], n[3], ctx, "down_blocks", 0, 600, "cosine", batch_pairs=2).cpu()
+    for i in range(2):
+        assert _rel(float(both[i]), want[i]) <= REL_F32, (i, float(both[i]), want[i])
+        one = ds.score_latent_pairs(zA[i:i + 1], zB[i:i + 1], n[2], n[3], ctx, "down_blocks", 0, 600, "cosine").cpu()
+        assert _rel(float(one[0]), want[i]) <= REL_F32, (i, float(one[0]), want[i])

@@ -1130,10 +1130,13 @@ __global__ __launch_bounds__(256, (D <= 80 ? 4 : 2)) void attn_short_kernel(cons
 
 // ---- fused score tail ----------------------------------------------------------------------
 // grid (ceil(N/128), B*H, n_pairs*2); partial layout [pair][dir][bh][qtile][4] f32
-// (16-bit modes up to d = 80: held to two workgroups per CU -- left alone hipcc parks copies in AGPRs, 276 registers at d = 72, one
-//  wave per SIMD; d = 160 keeps both outputs in f32, 426 registers: forcing it to 256 spills 215 of them inside the key loop, 0.50 -> 0.85 ms)
+// 16-bit modes (round 5): both SDPA outputs are rounded to the compute dtype before the products -- torch's SDPA returns
+// tensors of the pipeline dtype and the reference's cosine / mse consume those (diffsim.py:177-190); the products and sums stay
+// f32 per workgroup and f64 across them.  The self-attention's output then waits for the cross-attention as packed 16-bit
+// pairs (40 registers at d = 160 instead of 80), which brings d = 160 from 426 registers (one workgroup per CU) under 256: two
+// workgroups per CU.  The f32 parity mode keeps both outputs in f32.
 template <typename T, int D>
-__global__ __launch_bounds__(256, ((sizeof(T) == 2 && D <= 80) ? 2 : 1)) void pair_tail_kernel(const T* __restrict__ qg, const T* __restrict__ kg,
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void pair_tail_kernel(const T* __restrict__ qg, const T* __restrict__ kg,
                                                         const T* __restrict__ vg, const int32_t* __restrict__ idx_a,
                                                         const int32_t* __restrict__ idx_b, int B, int H, int N,
                                                         float scale_log2, int mse, float* __restrict__ part) {
@@ -1153,12 +1156,46 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 && D <= 80) ? 2 : 1)) void pa
     const size_t boff = (size_t)b * N * ld + h * D;
     QFrags<T, D> qf;
     load_q<T, D>(qf, qg + iq * img + boff + (size_t)qc * ld, half, scale_log2);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if constexpr (sizeof(T) == 2) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        h16x2 osp[C::NDB][8];           // the self-attention's output, rounded to the compute dtype, two values per register
+        {
+            OAcc<T, D> osa;
+            attend<T, D>(qf, kg + iq * img + boff, vg + iq * img + boff, ld, N, smem, osa);
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    osp[db][r >> 1] = __builtin_convertvector((f32x2){osa.b[db][r], osa.b[db][r + 1]}, h16x2);
+                    asm volatile("" : "+v"(osp[db][r >> 1]));          // (pinned: the f32 accumulators die here, before the second attention)
+                }
+        }
+        OAcc<T, D> oxa;
+        attend<T, D>(qf, kg + ix * img + boff, vg + ix * img + boff, ld, N, smem, oxa);
+        if (q < N) {
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const h16x2 xp = __builtin_convertvector((f32x2){oxa.b[db][r], oxa.b[db][r + 1]}, h16x2);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int rr = r + e, d = db * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+                        if (d < D) {
+                            const float x = (float)xp[e], y = (float)osp[db][r >> 1][e];
+                            if (mse) { const float df = x - y; s0 = fmaf(df, df, s0); }
+                            else { s0 = fmaf(x, y, s0); s1 = fmaf(x, x, s1); s2 = fmaf(y, y, s2); }
+                        }
+                    }
+                }
+        }
+    } else {
     OAcc<T, D> osa, oxa;
     attend<T, D>(qf, kg + iq * img + boff, vg + iq * img + boff, ld, N, smem, osa);
     attend<T, D>(qf, kg + ix * img + boff, vg + ix * img + boff, ld, N, smem, oxa);
     auto& os = osa.b;
     auto& ox = oxa.b;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     if (q < N) {
 #pragma unroll
         for (int db = 0; db < C::NDB; ++db)
@@ -1171,6 +1208,7 @@ __global__ __launch_bounds__(256, ((sizeof(T) == 2 && D <= 80) ? 2 : 1)) void pa
                     else { s0 = fmaf(x, y, s0); s1 = fmaf(x, x, s1); s2 = fmaf(y, y, s2); }
                 }
             }
+    }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

@@ -255,8 +255,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A0, 0, (int)p.a0_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A1 ? p.A1 : p.A0), 0, (int)p.a1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)p.w_bytes, 0x00020000);
+#ifdef DSIM_DEVTOOLS
+    // kbench ablations (timing only, outputs wrong): KB_GEXP bit 16 = residual loads dropped, bit 32 = output stores dropped
+    // (zero-record descriptors: the range check drops the access, the instruction stream stays)
+    const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (p.exp & 32) ? 0 : (int)p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual ? p.residual : p.out), 0, (p.exp & 16) ? 0 : (int)p.out_bytes, 0x00020000);
+#else
     const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)(p.residual ? p.residual : p.out), 0, (int)p.out_bytes, 0x00020000);
+#endif
 
     // ---- per-thread state of the tile being staged ---------------------------------------------
     int m0 = 0, n0 = 0;
@@ -431,6 +438,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     const bool has_res = EK == EK_RES || (SLOW && p.epi == EPI_RESIDUAL);
 
     STAMP_DECL;
+#ifdef DSIM_DEVTOOLS
+    // kbench experiment (KB_GEXP bits 8..11 = d): workgroups of odd XCD-slot parity start d x 4 us late, so that their epilogues
+    // (the tile's HBM phase) fall into the other half's K loops
+    if ((p.exp >> 8) & 15) {
+        if ((blockIdx.x >> 3) & 1) {
+            const int n = ((p.exp >> 8) & 15) * 2;         // s_sleep 127 ~ 8128 cycles ~ 2 us at 2 GHz... x 2 per unit
+            for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+#endif
     int vb = blockIdx.x;
     int tile_par = 0;                                   // parity of this workgroup's tile counter (bias buffer)
     int b0 = 0;                                         // staging buffer holding K stage 0 of the current tile

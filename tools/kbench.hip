@@ -310,6 +310,23 @@ static void bench_gn(const char* name, int B, int HW, int C, int iters, Timer& t
     const float ms = t.run([&] { st = launch_groupnorm(x, C, nullptr, 0, g, b, out, B, HW, 32, 1e-5f, 1, DSIM_BF16, sc, 0); }, iters);
     const double by = 3.0 * B * (double)HW * C * 2;
     printf("%-28s B=%3d HW=%5d C=%5d                 %8.3f ms  %7.1f GB/s  st=%d\n", name, B, HW, C, ms, by / ms / 1e6, st);
+    if (getenv("KB_GNCHUNK")) {      // statistics + apply per sub-batch of images (does the apply pass then read from the Infinity Cache?)
+        const int rounds = getenv("KB_ROUNDS") ? atoi(getenv("KB_ROUNDS")) : 5;
+        const int cs[5] = {B, 128, 64, 32, 16};
+        std::vector<std::vector<float>> msr(5);
+        for (int r = 0; r < rounds; ++r)
+            for (int k = 0; k < 5; ++k) {
+                const int cb = cs[k];
+                msr[k].push_back(t.run([&] {
+                    for (int b0 = 0; b0 < B; b0 += cb)
+                        st |= launch_groupnorm((const char*)x + (size_t)b0 * HW * C * 2, C, nullptr, 0, g, b, (char*)out + (size_t)b0 * HW * C * 2,
+                                               std::min(cb, B - b0), HW, 32, 1e-5f, 1, DSIM_BF16, sc, 0);
+                }, iters));
+            }
+        printf("  images per launch pair -> median ms:");
+        for (int k = 0; k < 5; ++k) { std::sort(msr[k].begin(), msr[k].end()); printf("  %d: %.3f", cs[k], msr[k][rounds / 2]); }
+        printf("\n");
+    }
     const float ms2 = t.run([&] { st = launch_layernorm(x, g, b, out, B * HW, C, 1e-5f, DSIM_BF16, 0); }, iters);
     printf("%-28s M=%7d C=%5d                        %8.3f ms  %7.1f GB/s  st=%d\n", (std::string(name) + "_ln").c_str(), B * HW, C, ms2,
            2.0 * B * (double)HW * C * 2 / ms2 / 1e6, st);
@@ -508,6 +525,7 @@ int main(int argc, char** argv) {
     bench_attn("attn_sdxl_cross_1024_d64", B2, 2, 20, 1024, 77, 64, iters, t);
     // ---- norms ----
     bench_gn("gn_64_320", B2, 4096, 320, iters, t);
+    bench_gn("gn_32_640", B2, 1024, 640, iters, t);
     bench_gn("gn_16_1280", B2, 256, 1280, iters, t);
     return 0;
 }

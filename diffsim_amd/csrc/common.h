@@ -23,6 +23,7 @@
 #define groupnorm_scratch_bytes groupnorm_scratch_bytes_f16
 #define groupnorm_passes groupnorm_passes_f16
 #define launch_groupnorm launch_groupnorm_f16
+#define launch_groupnorm_pre launch_groupnorm_pre_f16
 #define launch_layernorm launch_layernorm_f16
 #define launch_layernorm_mod launch_layernorm_mod_f16
 #define launch_softmax_rows launch_softmax_rows_f16
@@ -135,6 +136,9 @@ struct GemmArgs {
     int ldo = 0;
     int out_split = 0;                          // > 0 (plain linear only, % 320 == 0): output columns [j*split, (j+1)*split) go to the
     long long out_split_stride = 0;             //   tensor at out + j * out_split_stride bytes, each [M][ldo] (the tapped q | k | v)
+    float* gn_part = nullptr;                   // optional (16-bit 3x3 convs on 256 x 128 / 256 x 256 tiles): GroupNorm statistics of the OUTPUT from
+    int gn_hw = 0;                              //   the epilogue: [image][gn_hw / 64][N / 4][2] f32 (sum, sum of squares) per (wave's 64 rows, 4-channel
+                                                //   quad); gn_hw = rows per image (% 256 == 0).  launch_groupnorm_pre folds them.
     const void* zero_page = nullptr;            // >= 16 zero bytes (kept for ABI stability; padding now comes from OOB buffer reads)
     unsigned a0_bytes = 0, a1_bytes = 0, w_bytes = 0, out_bytes = 0;   // filled by launch_gemm: operand extents for the buffer descriptors
 #ifdef DSIM_DEVTOOLS
@@ -176,6 +180,19 @@ void gemm_skinny_tile(const GemmArgs& a, int* bm, int* bn);          // its tile
 int gemm_band_width(int tilesM, int tilesN, size_t w_tile_bytes);   // tile-order band width (L2 reuse of the weight tiles)
 void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn);   // the tile the problem's shape asks for
 void gemm_launch_tile(const GemmArgs& a, int dtype, int* bm, int* bn);   // ... and the instantiation launch_gemm picks for it (dtype: DSIM_F32 or a 16-bit one)
+
+// Can launch_gemm take GemmArgs.gn_part for this problem?  (16-bit 3x3 conv on a power-of-two output map whose tile is the 256-row
+// one with 128 or 256 columns, N a multiple of it, whole images per 256 rows.)  The executors ask with the geometry of ONE image:
+// where a single image already fills the chip's tiles, every batch size runs the same tiles and the statistics are batch-invariant.
+inline bool gemm_gn_stats_tile(const GemmArgs& a, int dtype) {
+    if (dtype == DSIM_F32 || a.mode != GEMM_CONV3 || a.epi == EPI_GEGLU || a.bias2 || a.Wout <= 0) return false;
+    const int hw = a.Hout * a.Wout;
+    if ((a.Wout & (a.Wout - 1)) || (hw & (hw - 1)) || hw % 256) return false;
+    if (gemm_skinny_applies(a)) return false;
+    int bm, bn;
+    gemm_launch_tile(a, dtype, &bm, &bn);
+    return bm == 256 && (bn == 128 || bn == 256) && a.N % bn == 0;
+}
 
 // weight repack kernels -- pack.hip  (src f32/h16/f16 diffusers layout -> packed compute dtype)
 int pack_linear(const void* src, int src_dtype, void* dst, int dst_dtype, int N, int K,
@@ -231,6 +248,8 @@ int groupnorm_passes(int C0, int C1, int HW, int groups, int dtype);    // 2 (on
 int launch_groupnorm(const void* x0, int C0, const void* x1, int C1, const float* gamma,
                      const float* beta, void* out, int B, int HW, int groups, float eps, int silu,
                      int dtype, void* scratch, hipStream_t s);
+int launch_groupnorm_pre(const void* x, int C, const float* gamma, const float* beta, void* out, int B, int HW, int groups, float eps,
+                         int silu, int dtype, void* scratch, const float* part32, int chunks, hipStream_t s);   // statistics from GemmArgs.gn_part
 int launch_layernorm(const void* x, const float* gamma, const float* beta, void* out, int M, int C,
                      float eps, int dtype, hipStream_t s);
 // LayerNorm without affine followed by adaLN modulate: y = LN(x) * (1 + scale[half]) + shift[half], half =
@@ -284,6 +303,8 @@ int launch_rowlin_f16(const RowLinArgs& a, hipStream_t s);
 int launch_ff_fused_f16(const FFArgs& a, hipStream_t s);
 int launch_groupnorm_f16(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta, void* out, int B, int HW,
                          int groups, float eps, int silu, int dtype, void* scratch, hipStream_t s);
+int launch_groupnorm_pre_f16(const void* x, int C, const float* gamma, const float* beta, void* out, int B, int HW, int groups, float eps,
+                             int silu, int dtype, void* scratch, const float* part32, int chunks, hipStream_t s);
 int launch_layernorm_f16(const void* x, const float* gamma, const float* beta, void* out, int M, int C, float eps, int dtype, hipStream_t s);
 int launch_layernorm_mod_f16(const void* x, const float* scale2, const float* shift2, void* out, int M, int C, int rows_per_batch, float eps,
                              int dtype, hipStream_t s);

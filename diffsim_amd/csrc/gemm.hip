@@ -217,11 +217,14 @@ constexpr int gemm_lds_bytes() {
 // EK (epilogue kind): EK_PLAIN bias only; EK_RES + residual; EK_SLOW the DiT epilogues (tanh-GELU activation, adaLN
 // gate, optional residual decided at run time).  Compile-time, because a run-time residual flag makes hipcc keep
 // every prefetched residual register in scratch, and the DiT math would add its register pressure to all users.
-enum { EK_PLAIN = 0, EK_RES = 1, EK_SLOW = 2, EK_ACT = 3 };   // EK_ACT: tanh-GELU only (DiT Mlp.fc1): no gate, no residual registers
-template <typename T, int BM, int BN, int MODE, bool GEGLU, int WM, int WN, int EK>
+enum { EK_PLAIN = 0, EK_RES = 1, EK_SLOW = 2, EK_ACT = 3,     // EK_ACT: tanh-GELU only (DiT Mlp.fc1): no gate, no residual registers
+       EK_PLAIN_GN = 4, EK_RES_GN = 5 };                        // + GroupNorm statistics of the output from the read-back (GemmArgs.gn_part)
+template <typename T, int BM, int BN, int MODE, bool GEGLU, int WM, int WN, int EKT>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p, const int tilesN, const int ntiles, const int tilesM,
                                                                const int gn) {
     constexpr int NW = WM * WN;
+    constexpr bool GNS = EKT >= EK_PLAIN_GN;               // epilogue statistics for the consumer's GroupNorm (the VAE's wide levels)
+    constexpr int EK = GNS ? EKT - EK_PLAIN_GN : EKT;      // the epilogue kind proper
     constexpr bool CONV = MODE != GEMM_LINEAR;             // GEMM_CONV3 or GEMM_CONV3P (output map sides are powers of two)
     constexpr bool P2 = MODE == GEMM_CONV3P;
     constexpr int BK = Traits<T>::BK;
@@ -626,6 +629,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
         // latency of its residual once, under the conversions, instead of once per 16-row slab (profiles/r05_experiments.txt item 2:
         // the slab-by-slab form was 31-42 % of a K = N <= 1280 launch against 12-17 % for the plain epilogue).
         constexpr bool RES16 = EK == EK_RES && sizeof(T) == 2 && !GEGLU && CONV;      // (linears: the slab-by-slab form measured 1-3 % faster)
+        // GroupNorm statistics of the STORED values (round 5, the VAE's 512 x 512 and 256 x 256 levels): a lane of the read-back
+        // always holds the same 16-byte chunk column (64 % CPR == 0), so it sums its two 4-channel quads over all its rows of the
+        // tile -- (sum, sum of squares) x 2 -- the lanes that share a column are folded by a fixed xor tree, and the wave's CPR
+        // first lanes write 2 x (sum, sumsq) each: one partial per (wave's 64 rows, quad), in a fixed place.  A fixed order per tile
+        // shape, and the tile shape is fixed per image size (the caller only asks for it where one image alone fills the chip), so the
+        // statistics are the same bits at every batch size.
+        float gq[4] = {0.f, 0.f, 0.f, 0.f};                // quad 0 sum, quad 1 sum, quad 0 sumsq, quad 1 sumsq
+        auto gn_acc = [&](const V16& o) {
+            if constexpr (GNS) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float f = (float)o[e];
+                    gq[e >> 2] += f;
+                    gq[2 + (e >> 2)] = fmaf(f, f, gq[2 + (e >> 2)]);
+                }
+            }
+        };
         if constexpr (RES16) {
             h16x4 pk[TM][TN];
             constexpr int HP = TM >= 2 ? TM / 2 : 1;               // slabs per half: pack a half, request its residual, pack the other half
@@ -674,6 +694,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                         const h16x2 pr = __builtin_convertvector((f32x2){(float)t[e] + (float)r[e], (float)t[e + 1] + (float)r[e + 1]}, h16x2);
                         o16[e] = pr[0]; o16[e + 1] = pr[1];
                     }
+                    if (lp[it] != OOB) gn_acc(o16);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o16), rO, (int)store_v(i, it), 0, 0);
                 }
             }
@@ -737,6 +758,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
             for (int it = 0; it < NIT; ++it) {
                 const V16 t = *reinterpret_cast<const V16*>(wst + lrd[it]);
                 if (!SLOW && !ACT && !has_res) {         // plain projection: LDS -> HBM copy
+                    if (lp[it] != OOB) gn_acc(t);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rOt, (int)store_v(i, it), 0, 0);
                     continue;
                 }
@@ -791,6 +813,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o16), rO, (int)store_v(i, it), 0, 0);
             }
         }
+        }
+        if constexpr (GNS) {
+            static_assert(sizeof(T) == 2 && CONV && !GEGLU && 64 % CPR == 0 && (CPR == 8 || CPR == 16), "epilogue statistics: 64- or 128-column wave tiles");
+            // fold the lanes that share a chunk column (lane % CPR): fixed tree over the upper lane bits
+#pragma unroll
+            for (int off = 32; off >= CPR; off >>= 1)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gq[k] += __shfl_xor(gq[k], off, 64);
+            int glane = lane;
+            asm volatile("" : "+v"(glane));
+            if (glane < CPR) {
+                const int img = em0 / p.gn_hw, chunk = ((em0 - img * p.gn_hw) / BM) * WM + wm_u;       // uniform
+                const int quads = p.N >> 2, q0 = ((en0 + wn_u * WBN) >> 2) + glane * 2;
+                float* o = p.gn_part + (((size_t)img * (p.gn_hw / (BM / WM)) + chunk) * quads + q0) * 2;
+                *reinterpret_cast<f32x4*>(o) = (f32x4){gq[0], gq[2], gq[1], gq[3]};
+            }
         }
         STAMP(st_[5]);
         STAMP_ACC(0); STAMP_ACC(1); STAMP_ACC(2); STAMP_ACC(3); STAMP_ACC(4);
@@ -905,6 +943,15 @@ int launch_one(const GemmArgs& a, hipStream_t s) {
         if (a.act == 1 && !a.gate && a.epi != EPI_RESIDUAL) return launch_ek<T, BM, BN, MODE, GEGLU, WM, WN, EK_ACT>(a, s);
         return launch_ek<T, BM, BN, MODE, GEGLU, WM, WN, EK_SLOW>(a, s);
     }
+    if constexpr (!GEGLU && sizeof(T) == 2 && MODE == GEMM_CONV3P && BM == 256 && (BN == 128 || BN == 256)) {
+        // GroupNorm statistics from the epilogue (GemmArgs.gn_part): the VAE's 512 x 512 / 256 x 256 levels on their 256-row tiles
+        if (a.gn_part) {
+            if (a.gn_hw <= 0 || a.gn_hw % BM || a.M % a.gn_hw || a.N % BN || a.bias2) return DSIM_ERR_INVALID;
+            return a.epi == EPI_RESIDUAL ? launch_ek<T, BM, BN, MODE, GEGLU, WM, WN, EK_RES_GN>(a, s)
+                                         : launch_ek<T, BM, BN, MODE, GEGLU, WM, WN, EK_PLAIN_GN>(a, s);
+        }
+    }
+    if (a.gn_part) return DSIM_ERR_INVALID;            // asked for on a tile that has no statistics epilogue (gemm_gn_stats_tile() says which)
     if constexpr (!GEGLU)
         if (a.epi == EPI_RESIDUAL) return launch_ek<T, BM, BN, MODE, GEGLU, WM, WN, EK_RES>(a, s);
     return launch_ek<T, BM, BN, MODE, GEGLU, WM, WN, EK_PLAIN>(a, s);
@@ -946,7 +993,7 @@ int launch_typed(const GemmArgs& a_in, hipStream_t s) {
     }
     if constexpr (sizeof(T) == 2) {
         // problems too small to fill the chip: 64 x 64 tiles behind a deep LDS ring, the same arithmetic bit for bit (gemm_skinny.hip)
-        if (g_gemm_skinny && gemm_skinny_applies(a)) {
+        if (g_gemm_skinny && !a.gn_part && gemm_skinny_applies(a)) {
             GemmArgs g = a;
             const int se = gemm_fill_extents(g, sizeof(T));
             return se != DSIM_OK ? se : launch_gemm_skinny(g, s);
@@ -966,7 +1013,9 @@ int launch_typed(const GemmArgs& a_in, hipStream_t s) {
             if (a.epi == EPI_GEGLU)
                 return bn == 320 ? launch_one<T, 256, 320, GEMM_LINEAR, true, 4, 2>(a, s) : launch_one<T, 256, 256, GEMM_LINEAR, true, 4, 2>(a, s);
             if (a.mode == GEMM_CONV3) {
-                if (bn == 128) return launch_one<T, 256, 128, GEMM_CONV3, false, 4, 2>(a, s);
+                // (the VAE's 128-channel levels: power-of-two maps as well -- setup()'s integer divisions were 10 % of these K = 1152 tiles)
+                if (bn == 128) return a.lwo >= 0 ? launch_one<T, 256, 128, GEMM_CONV3P, false, 4, 2>(a, s)
+                                                 : launch_one<T, 256, 128, GEMM_CONV3, false, 4, 2>(a, s);
                 // power-of-two output maps (every SD level at the sizes these tiles serve): the instantiation without the integer
                 // divisions in setup(); a run-time branch instead spilled scalar registers in the residual kernel
                 if (a.lwo >= 0) return bn == 320 ? launch_one<T, 256, 320, GEMM_CONV3P, false, 4, 2>(a, s)

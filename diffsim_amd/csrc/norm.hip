@@ -173,6 +173,38 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const T* __restric
     }
 }
 
+// Statistics from the producing conv's epilogue (gemm.hip, GemmArgs.gn_part): part32[b][chunk][quad][2] f32 = (sum, sum of squares) of
+// one wave's 64 rows x one 4-channel quad, chunk = (256-row tile of the image) x 4 + wave row.  One workgroup per (group, image) folds
+// them into out[b][0][g][2] (f64; the layout gn_apply_kernel reads with chunks = 1): thread t takes chunks t, t + 256, ... (the
+// group's quads in order inside a chunk), then a fixed xor-shuffle tree per wave and the four waves in order.
+__global__ __launch_bounds__(GN_THREADS) void gn_fold_kernel(const float* __restrict__ part32, int chunks, int quads, int groups,
+                                                             double* __restrict__ out) {
+    __shared__ double s_w[GN_THREADS / 64][2];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int qpg = quads / groups;
+    double a = 0.0, q = 0.0;
+    const float* src = part32 + ((size_t)b * chunks * quads + (size_t)g * qpg) * 2;
+    for (int c = tid; c < chunks; c += GN_THREADS)
+        for (int k = 0; k < qpg; ++k) {
+            const float2 pr = *reinterpret_cast<const float2*>(src + ((size_t)c * quads + k) * 2);
+            a += (double)pr.x;
+            q += (double)pr.y;
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        q += __shfl_xor(q, off, 64);
+    }
+    if ((tid & 63) == 0) { s_w[tid >> 6][0] = a; s_w[tid >> 6][1] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        a = 0.0; q = 0.0;
+        for (int w = 0; w < GN_THREADS / 64; ++w) { a += s_w[w][0]; q += s_w[w][1]; }
+        out[((size_t)b * groups + g) * 2] = a;
+        out[((size_t)b * groups + g) * 2 + 1] = q;
+    }
+}
+
 // grid (row_blocks, B)
 template <typename T, bool SILU, int NS, int UNR>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const T* __restrict__ x0, int C0,
@@ -682,7 +714,14 @@ int gn_onepass_slab(int C0, int C1, int B, int HW, int groups) {
 
 template <typename T, int NS, int UNR>
 int gn_launch(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta, void* out, int B,
-              int HW, int groups, float eps, int silu, void* scratch, int chunks, int rb, size_t lds, hipStream_t s) {
+              int HW, int groups, float eps, int silu, void* scratch, int chunks, int rb, size_t lds, hipStream_t s,
+              const float* pre = nullptr, int pre_chunks = 0) {
+    if (pre) {
+        // the statistics pass already happened in the producing conv's epilogue (GemmArgs.gn_part): fold its per-(wave, 4-channel quad)
+        // f32 partials into one f64 pair per (image, group), in fixed order
+        hipLaunchKernelGGL(gn_fold_kernel, dim3(groups, B), dim3(GN_THREADS), 0, s, pre, pre_chunks, (C0 + C1) / 4, groups, (double*)scratch);
+        chunks = 1;
+    } else
     hipLaunchKernelGGL((gn_stats_kernel<T, NS, UNR>), dim3(chunks, B), dim3(GN_THREADS), lds, s, (const T*)x0, C0,
                        (const T*)x1, C1, HW, groups, (double*)scratch);
     const size_t alds = (size_t)chunks * groups * 2 * sizeof(double);       // <= 32 KB
@@ -698,13 +737,16 @@ int gn_launch(const void* x0, int C0, const void* x1, int C1, const float* gamma
 
 template <typename T>
 int gn_typed(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta,
-             void* out, int B, int HW, int groups, float eps, int silu, void* scratch, hipStream_t s) {
+             void* out, int B, int HW, int groups, float eps, int silu, void* scratch, hipStream_t s,
+             const float* pre = nullptr, int pre_chunks = 0) {
     constexpr int VEC = Vec16<T>::N;
     const int C = C0 + (x1 ? C1 : 0);
     if (!x1) C1 = 0;
     if (C % groups || C0 % VEC || C1 % VEC || groups > 64 || C > GN_MAX_SLOTS * GN_THREADS * VEC)
         return DSIM_ERR_INVALID;
-    if (const int CS = g_gn_onepass ? gn_onepass_slab<T>(C0, C1, B, HW, groups) : 0) {
+    // (precomputed statistics: whole 4-channel quads per group)
+    if (pre && (x1 || groups > 64 || (C / groups) % 4)) return DSIM_ERR_INVALID;
+    if (const int CS = (g_gn_onepass && !pre) ? gn_onepass_slab<T>(C0, C1, B, HW, groups) : 0) {
         const int tpr1 = CS / VEC, R1 = GN_THREADS / tpr1;
         const size_t lds1 = (size_t)R1 * CS * 2 * sizeof(float);
         if (silu)
@@ -728,11 +770,11 @@ int gn_typed(const void* x0, int C0, const void* x1, int C1, const float* gamma,
     rb = rb < 1 ? 1 : (rb > 64 ? 64 : rb);
     const int ns = (S + tpr - 1) / tpr;
     if (ns == 1)
-        return gn_launch<T, 1, 4>(x0, C0, x1, C1, gamma, beta, out, B, HW, groups, eps, silu, scratch, chunks, rb, lds, s);
+        return gn_launch<T, 1, 4>(x0, C0, x1, C1, gamma, beta, out, B, HW, groups, eps, silu, scratch, chunks, rb, lds, s, pre, pre_chunks);
     if (ns == 2)
-        return gn_launch<T, 2, 2>(x0, C0, x1, C1, gamma, beta, out, B, HW, groups, eps, silu, scratch, chunks, rb, lds, s);
+        return gn_launch<T, 2, 2>(x0, C0, x1, C1, gamma, beta, out, B, HW, groups, eps, silu, scratch, chunks, rb, lds, s, pre, pre_chunks);
     return gn_launch<T, GN_MAX_SLOTS, 1>(x0, C0, x1, C1, gamma, beta, out, B, HW, groups, eps, silu, scratch, chunks, rb,
-                                         lds, s);
+                                         lds, s, pre, pre_chunks);
 }
 
 }  // namespace
@@ -745,6 +787,18 @@ int groupnorm_passes(int C0, int C1, int HW, int groups, int dtype) {
 }
 
 size_t groupnorm_scratch_bytes(int B, int groups) { return (size_t)B * 64 * groups * 2 * sizeof(double); }
+
+// GroupNorm(+SiLU) whose statistics pass already ran in the producing conv's epilogue: part32 = GemmArgs.gn_part of that launch,
+// chunks = its partial rows per image (HW / 64); 16-bit dtypes only
+int launch_groupnorm_pre(const void* x, int C, const float* gamma, const float* beta, void* out, int B, int HW, int groups, float eps,
+                         int silu, int dtype, void* scratch, const float* part32, int chunks, hipStream_t s) {
+    if (!part32 || chunks < 1) return DSIM_ERR_INVALID;
+    if (dtype == DSIM_H16) return gn_typed<h16>(x, C, nullptr, 0, gamma, beta, out, B, HW, groups, eps, silu, scratch, s, part32, chunks);
+#if !defined(DSIM_H16_IS_F16) && defined(DSIM_HAS_F16_TWINS)
+    if (dtype == DSIM_F16) return launch_groupnorm_pre_f16(x, C, gamma, beta, out, B, HW, groups, eps, silu, dtype, scratch, part32, chunks, s);
+#endif
+    return DSIM_ERR_INVALID;
+}
 
 int launch_groupnorm(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta,
                      void* out, int B, int HW, int groups, float eps, int silu, int dtype, void* scratch,

@@ -93,19 +93,41 @@ struct VWalk {
         g.epi = residual ? EPI_RESIDUAL : EPI_NONE; g.residual = residual; g.out = out; g.ldo = N;
         return gemm(g);
     }
+    // GroupNorm statistics of a conv's output from its epilogue (GemmArgs.gn_part) where ONE image alone fills the chip's 256-row
+    // tiles (the 512 x 512 and 256 x 256 levels: the same tiles at every batch size, so the numbers do not depend on the batch);
+    // `stats` receives the partial buffer for the GroupNorm that consumes the output (null: that GroupNorm runs its own pass)
     int conv3(const Act& x, const Packed* w, const float* bias, const void* residual, void* out, int Cout, int stride,
-              int pad, int batch) {
+              int pad, int batch, float** stats = nullptr) {
         GemmArgs g;
         g.A0 = x.p; g.C0 = x.C; g.mode = GEMM_CONV3; g.Hin = x.H; g.Win = x.W;
         g.Hout = stride == 2 ? x.H / 2 : x.H; g.Wout = stride == 2 ? x.W / 2 : x.W;
         g.stride = stride; g.ups = 0; g.pad = pad;
         g.M = batch * g.Hout * g.Wout; g.N = Cout; g.K = 9 * x.C; g.W = w->p; g.bias = bias;
         g.epi = residual ? EPI_RESIDUAL : EPI_NONE; g.residual = residual; g.out = out; g.ldo = Cout;
+        if (stats) {
+            *stats = nullptr;
+            const int hw = g.Hout * g.Wout, cpg = Cout / h->cfg.norm_num_groups;
+            GemmArgs one = g;
+            one.M = hw;                                          // the geometry of a single image
+            if (h->cfg.norm_num_groups == 32 && Cout % 32 == 0 && (cpg == 4 || cpg == 8 || cpg == 16) && gemm_gn_stats_tile(one, h->dt)) {
+                *stats = (float*)ar->alloc((size_t)batch * (hw / 64) * (Cout / 4) * 2 * sizeof(float));
+                g.gn_part = *stats;
+                g.gn_hw = hw;
+            }
+        }
         return gemm(g);
     }
-    int gn(const Act& x, const Packed* g, const Packed* b, void* out, int silu) {
+    int gn(const Act& x, const Packed* g, const Packed* b, void* out, int silu, const float* stats = nullptr) {
         if (!run) return DSIM_OK;
         const int HW = x.H * x.W;
+        if (stats) {
+            pbegin(std::string("groupnorm_pre_") + dtn() + "|B" + std::to_string(n) + " HW" + std::to_string(HW) + " C" + std::to_string(x.C), 0.0,
+                   2.0 * n * HW * (double)x.C * es());
+            const int st = launch_groupnorm_pre(x.p, x.C, (const float*)g->p, (const float*)b->p, out, n, HW, h->cfg.norm_num_groups, 1e-6f,
+                                                silu, h->dt, gn_scratch, stats, HW / 64, s);
+            pend();
+            return st;
+        }
         pbegin(std::string("groupnorm_") + dtn() + "|B" + std::to_string(n) + " HW" + std::to_string(HW) + " C" + std::to_string(x.C), 0.0,
                (double)groupnorm_passes(x.C, 0, HW, h->cfg.norm_num_groups, h->dt) * n * HW * (double)x.C * es());
         const int st = launch_groupnorm(x.p, x.C, nullptr, 0, (const float*)g->p, (const float*)b->p, out, n, HW,
@@ -114,21 +136,33 @@ struct VWalk {
         return st;
     }
 
-    int resnet(const std::string& p, const Act& x, int Cout, Act* out) {
+    // in_stats: epilogue statistics of x (from the conv that produced it) for norm1; out_stats: receives those of this block's output
+    int resnet(const std::string& p, const Act& x, int Cout, Act* out, const float* in_stats = nullptr, float** out_stats = nullptr) {
         const int Cin = x.C, M = n * x.H * x.W;
         VGET(n1w, p + "norm1.weight"); VGET(n1b, p + "norm1.bias");
         VGET(c1w, p + "conv1.weight"); VGET(c1b, p + "conv1.bias");
         VGET(n2w, p + "norm2.weight"); VGET(n2b, p + "norm2.bias");
         VGET(c2w, p + "conv2.weight"); VGET(c2b, p + "conv2.bias");
         out->p = alloc_act((size_t)M * Cout); out->C = Cout; out->H = x.H; out->W = x.W;
+        // (the output's statistics buffer outlives this block's scratch: allocated before the mark)
+        float* ostat = nullptr;
+        {
+            GemmArgs one;
+            one.mode = GEMM_CONV3; one.Hout = x.H; one.Wout = x.W; one.Hin = x.H; one.Win = x.W; one.C0 = Cout; one.M = x.H * x.W; one.N = Cout;
+            one.K = 9 * Cout; one.epi = EPI_RESIDUAL;
+            const int cpg = Cout / h->cfg.norm_num_groups;
+            if (out_stats && h->cfg.norm_num_groups == 32 && Cout % 32 == 0 && (cpg == 4 || cpg == 8 || cpg == 16) && gemm_gn_stats_tile(one, h->dt))
+                ostat = (float*)ar->alloc((size_t)n * (x.H * x.W / 64) * (Cout / 4) * 2 * sizeof(float));
+        }
         const size_t mk = ar->mark();
         Act t1{alloc_act((size_t)M * Cin), Cin, x.H, x.W};
-        CK(gn(x, n1w, n1b, t1.p, 1));
+        CK(gn(x, n1w, n1b, t1.p, 1, in_stats));
         Act t2{alloc_act((size_t)M * Cout), Cout, x.H, x.W};
-        CK(conv3(t1, c1w, (const float*)c1b->p, nullptr, t2.p, Cout, 1, 1, n));
+        float* st2 = nullptr;
+        CK(conv3(t1, c1w, (const float*)c1b->p, nullptr, t2.p, Cout, 1, 1, n, &st2));
         Act t3{t1.p, Cout, x.H, x.W};
         if (Cout > Cin) t3.p = alloc_act((size_t)M * Cout);
-        CK(gn(t2, n2w, n2b, t3.p, 1));
+        CK(gn(t2, n2w, n2b, t3.p, 1, st2));
         const void* res = x.p;
         if (Cin != Cout) {
             VGET(scw, p + "conv_shortcut.weight"); VGET(scb, p + "conv_shortcut.bias");
@@ -136,7 +170,16 @@ struct VWalk {
             CK(linear(x.p, Cin, scw->p, (const float*)scb->p, nullptr, sc, M, Cout));
             res = sc;
         }
-        CK(conv3(t3, c2w, (const float*)c2b->p, res, out->p, Cout, 1, 1, n));
+        {
+            // conv2 + residual; its epilogue statistics (for the next block's norm1) go to the buffer reserved above
+            GemmArgs g;
+            g.A0 = t3.p; g.C0 = t3.C; g.mode = GEMM_CONV3; g.Hin = g.Hout = x.H; g.Win = g.Wout = x.W; g.stride = 1; g.ups = 0; g.pad = 1;
+            g.M = M; g.N = Cout; g.K = 9 * t3.C; g.W = c2w->p; g.bias = (const float*)c2b->p;
+            g.epi = EPI_RESIDUAL; g.residual = res; g.out = out->p; g.ldo = Cout;
+            if (ostat) { g.gn_part = ostat; g.gn_hw = x.H * x.W; }
+            CK(gemm(g));
+        }
+        if (out_stats) *out_stats = ostat;
         ar->release(mk);
         return DSIM_OK;
     }
@@ -189,19 +232,25 @@ struct VWalk {
             pend();
             CK(st);
         }
+        float* xstat = nullptr;                 // epilogue statistics of x, when its producer made them
         for (int i = 0; i < nl; ++i) {
             const int co = c.block_out_channels[i];
             const std::string bp = "encoder.down_blocks." + std::to_string(i) + ".";
             for (int j = 0; j < c.layers_per_block; ++j) {
                 Act r;
-                CK(resnet(bp + "resnets." + std::to_string(j) + ".", x, co, &r));
+                float* rstat = nullptr;
+                // (the last resnet of a level feeds the downsample conv, not a GroupNorm: no statistics asked of it)
+                CK(resnet(bp + "resnets." + std::to_string(j) + ".", x, co, &r, xstat, j + 1 < c.layers_per_block ? &rstat : nullptr));
                 x = r;
+                xstat = rstat;
             }
             if (i != nl - 1) {
                 VGET(dw, bp + "downsamplers.0.conv.weight"); VGET(db, bp + "downsamplers.0.conv.bias");
                 Act d{alloc_act((size_t)n * (x.H / 2) * (x.W / 2) * co), co, x.H / 2, x.W / 2};
-                CK(conv3(x, dw, (const float*)db->p, nullptr, d.p, co, 2, 0, n));
+                CK(conv3(x, dw, (const float*)db->p, nullptr, d.p, co, 2, 0, n, &xstat));
                 x = d;
+            } else {
+                xstat = nullptr;
             }
         }
         {

@@ -306,3 +306,30 @@ def test_fp32_tap_at_the_320_channel_level_with_many_rows():
         assert _rel(float(both[i]), want[i]) <= REL_F32, (i, float(both[i]), want[i])
         one = ds.score_latent_pairs(zA[i:i + 1], zB[i:i + 1], n[2], n[3], ctx, "down_blocks", 0, 600, "cosine").cpu()
         assert _rel(float(one[0]), want[i]) <= REL_F32, (i, float(one[0]), want[i])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_vae_512px_epilogue_statistics_are_batch_invariant(dtype):
+    """The 512 x 512 and 256 x 256 levels of the VAE take their GroupNorm statistics from the producing conv's epilogue
+    (GemmArgs.gn_part: per-tile partials in a fixed order, folded in f64).  One image alone fills those levels' 256-row tiles, so
+    the tiles -- and with them every partial sum -- are the same at every batch size: the moments of an image are the same bits
+    alone, first in a batch of three and last in a batch of three; and they stay within the 16-bit bound of the oracle."""
+    from oracle import cpu_ref as R
+    from diffsim_amd.engine import VAEEncoder
+    cfg = C.VAE_SD15
+    sd = S.make_state_dict(cfg, seed=3)
+    a, b = S.make_image_pair(0, 512)
+    c, _ = S.make_image_pair(1, 512)
+    enc = VAEEncoder(cfg, sd, dtype)
+    one = enc.moments(a)
+    three = enc.moments(torch.cat([a, b, c]))
+    assert torch.equal(one[0], three[0])
+    assert torch.equal(enc.moments(torch.cat([c, b, a]))[2], one[0])
+    assert torch.equal(enc.moments(b)[0], three[1])
+    ref = R.AutoencoderKLEncoder(R.VAE_SD15)
+    ref.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+    ref.eval()
+    with torch.no_grad():
+        want = ref.moments(a)
+    err = (one.cpu() - want).abs().max().item()
+    assert err <= (6e-2 if dtype == torch.bfloat16 else 1.5e-2) * max(float(want.abs().max()), 1.0), err

@@ -487,6 +487,15 @@ int main(int argc, char** argv) {
     bench_gemm("conv3_16_2560_1280", GEMM_CONV3, s16, 1280, 2560, 16, 16, EPI_NONE, iters, t, zp);
     bench_gemm("conv3_8_1280_1280", GEMM_CONV3, s8, 1280, 1280, 8, 8, EPI_RESIDUAL, iters, t, zp);
     bench_gemm("conv3_8_2560_1280", GEMM_CONV3, s8, 1280, 2560, 8, 8, EPI_NONE, iters, t, zp);
+    // ---- the VAE encoder's widest levels (pixels-in path): B2 / 16 images at 512 px ----
+    {
+        const int vi = std::max(1, B2 / 16);
+        bench_gemm("conv3_vae512_128_128", GEMM_CONV3, vi * 512 * 512, 128, 128, 512, 512, EPI_NONE, iters, t, zp);
+        bench_gemm("conv3_vae512_128_128_res", GEMM_CONV3, vi * 512 * 512, 128, 128, 512, 512, EPI_RESIDUAL, iters, t, zp);
+        bench_gemm("conv3_vae256_128_256", GEMM_CONV3, vi * 256 * 256, 256, 128, 256, 256, EPI_NONE, iters, t, zp);
+        bench_gemm("conv3_vae256_256_256_res", GEMM_CONV3, vi * 256 * 256, 256, 256, 256, 256, EPI_RESIDUAL, iters, t, zp);
+        bench_gemm("conv3_vae128_512_512_res", GEMM_CONV3, vi * 128 * 128, 512, 512, 128, 128, EPI_RESIDUAL, iters, t, zp);
+    }
     // ---- linears ----
     bench_gemm("lin_64_320_320_res", GEMM_LINEAR, s64, 320, 320, 0, 0, EPI_RESIDUAL, iters, t, zp);
     bench_gemm("lin_64_320_960_qkv", GEMM_LINEAR, s64, 960, 320, 0, 0, EPI_NONE, iters, t, zp);

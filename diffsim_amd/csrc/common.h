@@ -136,6 +136,8 @@ struct GemmArgs {
     int ldo = 0;
     int out_split = 0;                          // > 0 (plain linear only, % 320 == 0): output columns [j*split, (j+1)*split) go to the
     long long out_split_stride = 0;             //   tensor at out + j * out_split_stride bytes, each [M][ldo] (the tapped q | k | v)
+    int wb_rows = 0;                            // optional (GEMM_LINEAR): batched weights -- rows [i * wb_rows, (i + 1) * wb_rows) multiply the
+    unsigned wb_stride = 0;                     //   [N][K] matrix at W + i * wb_stride bytes (the VAE's per-image q k^T and P v); M % wb_rows == 0
     float* gn_part = nullptr;                   // optional (16-bit 3x3 convs on 256 x 128 / 256 x 256 tiles): GroupNorm statistics of the OUTPUT from
     int gn_hw = 0;                              //   the epilogue: [image][gn_hw / 64][N / 4][2] f32 (sum, sum of squares) per (wave's 64 rows, 4-channel
                                                 //   quad); gn_hw = rows per image (% 256 == 0).  launch_groupnorm_pre folds them.
@@ -214,6 +216,11 @@ int sincos_values(float* out, int dim, const float* vals /*device*/, int count, 
 int prep_conv_in(const float* lat, const float* noise /*nullable*/, float sa, float sb, const float* w /*[9*Cin][Cout]*/,
                  const float* bias, void* out, int dtype, int n_img, int Cin, int S, int Cout, int dup /*1|2*/,
                  hipStream_t st);
+// the VAE's 3 -> 128 conv_in at image resolution, one 64-pixel row segment per workgroup (bit-identical to prep_conv_in); gn_part
+// (16-bit dtypes only, nullable): the consumer's GroupNorm statistics in the conv epilogue's format (launch_groupnorm_pre)
+bool conv_in_rows_applies(int Cin, int S, int Cout);
+int conv_in_rows(const float* images, const float* w /*[27][128]*/, const float* bias, void* out, int dtype, int n_img, int S,
+                 float* gn_part, hipStream_t st);
 int convert_f32_to(const float* src, void* dst, int dtype, size_t n, hipStream_t s);
 // out[2b], out[2b+1] = in[b]: a batch element becomes its two classifier-free-guidance copies (bytes_per_elem % 16 == 0)
 int dup_batch(const void* in, void* out, int n_batch, size_t bytes_per_elem, hipStream_t s);

@@ -315,10 +315,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                 a_voff[i] = (m < p.M) ? (unsigned)m * (unsigned)p.C0 * (unsigned)sizeof(T) + celb : OOB;
             }
         }
+        // batched weights (the VAE's per-image q k^T and P v): the tile's rows belong to ONE batch (wb_rows % BM == 0)
+        const unsigned wofs = (!CONV && p.wb_rows) ? (unsigned)(m0 / p.wb_rows) * p.wb_stride : 0u;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int n = n0 + i * (NW * 8) + wrow;
-            b_voff[i] = (n < p.N) ? (unsigned)n * (unsigned)p.K * (unsigned)sizeof(T) + celb : OOB;
+            b_voff[i] = (n < p.N) ? wofs + (unsigned)n * (unsigned)p.K * (unsigned)sizeof(T) + celb : OOB;
         }
     };
     // B pieces this wave really issues per stage (wave-uniform): the tail piece exists only for
@@ -896,7 +898,7 @@ int gemm_fill_extents(GemmArgs& g, size_t es) {
         a0b = (size_t)g.M * g.C0 * es;
         if (g.A1) a1b = (size_t)g.M * g.C1 * es;
     }
-    const size_t wb = (size_t)g.N * g.K * es;
+    const size_t wb = (size_t)g.N * g.K * es + (g.wb_rows ? (size_t)(g.M / g.wb_rows - 1) * g.wb_stride : 0);
     const size_t ob = (size_t)g.M * g.ldo * es;        // output (and residual) extent: rows are ldo elements apart
     if (a0b >= 0x7fffffffull || a1b >= 0x7fffffffull || wb >= 0x7fffffffull || ob >= 0x7fffffffull) return DSIM_ERR_INVALID;
     g.a0_bytes = (unsigned)a0b; g.a1_bytes = (unsigned)a1b; g.w_bytes = (unsigned)wb; g.out_bytes = (unsigned)ob;
@@ -967,6 +969,9 @@ int check_args(const GemmArgs& a, int BK) {
     if (a.epi == EPI_GEGLU && (a.mode != GEMM_LINEAR || (a.geglu_blk == 16 ? a.N % 320 != 0 : (a.geglu_blk != 32 || a.N % 64))))
         return DSIM_ERR_INVALID;
     if (!a.zero_page) return DSIM_ERR_INVALID;
+    if (a.wb_rows && (a.wb_rows < 0 || a.mode != GEMM_LINEAR || a.M % a.wb_rows || a.A1 || a.epi == EPI_GEGLU || a.out_split ||
+                      a.wb_stride % 16))
+        return DSIM_ERR_INVALID;
     if (a.mode == GEMM_CONV3 && a.epi == EPI_RESIDUAL && a.bias2) return DSIM_ERR_INVALID;      // per-half bias: plain convs only (conv1 of a resnet)
     if (a.out_split && (a.mode != GEMM_LINEAR || a.epi != EPI_NONE || a.act || a.gate || a.out_split % 320 || a.N % a.out_split ||
                         a.out_split_stride <= 0 || (a.N / a.out_split) * a.out_split_stride >= 0x7fffffffll))
@@ -991,9 +996,10 @@ int launch_typed(const GemmArgs& a_in, hipStream_t s) {
             while ((1 << a.lhw) < hw) ++a.lhw;
         }
     }
+    if (a.wb_rows == a.M) a.wb_rows = 0;        // one batch: a plain GEMM
     if constexpr (sizeof(T) == 2) {
         // problems too small to fill the chip: 64 x 64 tiles behind a deep LDS ring, the same arithmetic bit for bit (gemm_skinny.hip)
-        if (g_gemm_skinny && !a.gn_part && gemm_skinny_applies(a)) {
+        if (g_gemm_skinny && !a.gn_part && !a.wb_rows && gemm_skinny_applies(a)) {
             GemmArgs g = a;
             const int se = gemm_fill_extents(g, sizeof(T));
             return se != DSIM_OK ? se : launch_gemm_skinny(g, s);
@@ -1005,6 +1011,7 @@ int launch_typed(const GemmArgs& a_in, hipStream_t s) {
     gemm_launch_tile(a, sizeof(T) == 2 ? DSIM_H16 : DSIM_F32, &bm, &bn);
     // out_split: the epilogue picks ONE destination tensor per tile from its first column, so the tile width must divide the split
     if (a.out_split && a.out_split % bn != 0) return DSIM_ERR_INVALID;
+    if (a.wb_rows % bm != 0) return DSIM_ERR_INVALID;           // a tile's rows belong to one weight batch
     const bool big = bm == 256, n160 = bn == 160;
     (void)big;
     if constexpr (sizeof(T) == 2) {

@@ -102,7 +102,7 @@ struct WeightStore {
 static inline std::string gemm_family(const GemmArgs& g, int dt, double* flops, double* bytes) {
     int bm, bn;
     gemm_launch_tile(g, dt, &bm, &bn);
-    const bool skinny = dt != DSIM_F32 && gemm_skinny_applies(g);      // the small-batch kernel (gemm_skinny.hip)
+    const bool skinny = dt != DSIM_F32 && !(g.wb_rows && g.wb_rows != g.M) && gemm_skinny_applies(g);      // the small-batch kernel (gemm_skinny.hip)
     // 256-row 16-bit conv tiles on power-of-two output maps run the CONV3P instantiation (gemm.hip launch_typed)
     const int hwo = g.Hout * g.Wout;
     const bool conv_p2 = g.mode == GEMM_CONV3 && !skinny && dt != DSIM_F32 && bm == 256 && g.Wout > 0 &&
@@ -112,7 +112,8 @@ static inline std::string gemm_family(const GemmArgs& g, int dt, double* flops, 
     const double e = (double)dtype_size(dt);
     const double outc = g.epi == EPI_GEGLU ? g.N / 2 : g.N;
     *flops = 2.0 * g.M * (double)g.N * g.K;
-    *bytes = e * ((double)g.M * (g.mode == GEMM_CONV3 ? g.C0 : g.K) + (double)g.N * g.K + (double)g.M * outc * (g.residual ? 2 : 1));
+    *bytes = e * ((double)g.M * (g.mode == GEMM_CONV3 ? g.C0 : g.K) + (double)g.N * g.K * (g.wb_rows ? g.M / g.wb_rows : 1) +
+                  (double)g.M * outc * (g.residual ? 2 : 1));
     return std::string(skinny ? "gemm_small_" : "gemm_") + dtn + "_" + std::to_string(bm) + "x" + std::to_string(bn) +
            (g.mode == GEMM_CONV3 ? (conv_p2 ? "_conv3p" : "_conv3") : "_linear") +
            (g.epi == EPI_GEGLU ? "_geglu" : (g.epi == EPI_RESIDUAL ? "_res" : "")) +

@@ -200,19 +200,36 @@ struct VWalk {
         char* o = (char*)alloc_act((size_t)M * C);
         CK(linear(t, C, wq->p, (const float*)bq->p, nullptr, q, M, C));
         CK(linear(t, C, wk->p, (const float*)bk->p, nullptr, k, M, C));
-        void* sc = alloc_act((size_t)N * N);                  // one image's score matrix
-        void* vT = alloc_act((size_t)C * N);
+        // Images per group: the score matrices of a whole group come from ONE batched launch each way (GemmArgs.wb_rows: row block i
+        // multiplies image i's k / v^T), so the 32-tile P v of a single 4096-token image no longer runs as 16 x n quarter-chip
+        // launches; same tiles' arithmetic bit for bit (gemm_skinny_kernel == gemm_kernel, asserted in the tests), so an image's
+        // moments do not depend on its group.  Token counts that are not whole 256-row tiles keep one image per launch.
+        int grp = 1;
+        if (N % 256 == 0) {
+            const size_t lim = 0x7fffffffull / ((size_t)N * N * es());
+            grp = (int)std::min<size_t>((size_t)n, lim < 1 ? 1 : lim);
+        }
+        void* sc = alloc_act((size_t)grp * N * N);             // the group's score matrices
+        char* vT = (char*)alloc_act((size_t)grp * C * N);
         const size_t img = (size_t)N * C * es();
-        for (int i = 0; i < n; ++i) {
-            CK(linear(q + i * img, C, k + i * img, nullptr, nullptr, sc, N, N));                  // S = q k^T
+        for (int i0 = 0; i0 < n; i0 += grp) {
+            const int gi = std::min(grp, n - i0);
+            for (int i = 0; i < gi; ++i)
+                CK(linear(wv->p, C, t + (i0 + i) * img, nullptr, nullptr, vT + i * img, C, N));       // v^T = Wv x^T
+            GemmArgs g;
+            g.A0 = q + i0 * img; g.C0 = C; g.mode = GEMM_LINEAR; g.M = gi * N; g.N = N; g.K = C; g.W = k + i0 * img;
+            g.epi = EPI_NONE; g.out = sc; g.ldo = N; g.wb_rows = N; g.wb_stride = (unsigned)img;
+            CK(gemm(g));                                                                              // S = q k^T
             if (run) {
-                pbegin(std::string("softmax_rows_") + dtn() + "|N" + std::to_string(N), 0.0, 2.0 * N * (double)N * es());
-                const int st = launch_softmax_rows(sc, sc, N, N, 1.0f / sqrtf((float)C), h->dt, s);
+                pbegin(std::string("softmax_rows_") + dtn() + "|N" + std::to_string(N), 0.0, 2.0 * gi * N * (double)N * es());
+                const int st = launch_softmax_rows(sc, sc, gi * N, N, 1.0f / sqrtf((float)C), h->dt, s);
                 pend();
                 CK(st);
             }
-            CK(linear(wv->p, C, t + i * img, nullptr, nullptr, vT, C, N));                          // v^T = Wv x^T
-            CK(linear(sc, N, vT, (const float*)bv->p, nullptr, o + i * img, N, C));                // O = P v + b_v
+            GemmArgs o2;
+            o2.A0 = sc; o2.C0 = N; o2.mode = GEMM_LINEAR; o2.M = gi * N; o2.N = C; o2.K = N; o2.W = vT; o2.bias = (const float*)bv->p;
+            o2.epi = EPI_NONE; o2.out = o + i0 * img; o2.ldo = C; o2.wb_rows = N; o2.wb_stride = (unsigned)img;
+            CK(gemm(o2));                                                                             // O = P v + b_v
         }
         CK(linear(o, C, wo->p, (const float*)bo->p, x.p, out->p, M, C));
         ar->release(mk);
@@ -225,14 +242,19 @@ struct VWalk {
         gn_scratch = ar->alloc(groupnorm_scratch_bytes(n, c.norm_num_groups));
         VGET(ciw, "encoder.conv_in.weight"); VGET(cib, "encoder.conv_in.bias");
         Act x{alloc_act((size_t)n * S * S * ch0), ch0, S, S};
+        float* xstat = nullptr;                 // epilogue statistics of x, when its producer made them
+        const bool rows = conv_in_rows_applies(c.in_channels, S, ch0);
+        if (rows && h->dt != DSIM_F32 && c.norm_num_groups == 32)       // (one 4-channel quad per group at 128 channels)
+            xstat = (float*)ar->alloc((size_t)n * (S * S / 64) * (ch0 / 4) * 2 * sizeof(float));
         if (run) {
-            pbegin("prep_conv_in", 2.0 * n * S * S * (double)ch0 * 9 * c.in_channels, (double)n * S * S * (ch0 * es() + c.in_channels * 4.0));
-            const int st = prep_conv_in(images, nullptr, 1.f, 0.f, (const float*)ciw->p, (const float*)cib->p, x.p, h->dt, n,
-                                        c.in_channels, S, ch0, 1, s);
+            pbegin(rows ? "conv_in_rows" : "prep_conv_in", 2.0 * n * S * S * (double)ch0 * 9 * c.in_channels,
+                   (double)n * S * S * (ch0 * es() + c.in_channels * 4.0));
+            const int st = rows ? conv_in_rows(images, (const float*)ciw->p, (const float*)cib->p, x.p, h->dt, n, S, xstat, s)
+                                : prep_conv_in(images, nullptr, 1.f, 0.f, (const float*)ciw->p, (const float*)cib->p, x.p, h->dt, n,
+                                               c.in_channels, S, ch0, 1, s);
             pend();
             CK(st);
         }
-        float* xstat = nullptr;                 // epilogue statistics of x, when its producer made them
         for (int i = 0; i < nl; ++i) {
             const int co = c.block_out_channels[i];
             const std::string bp = "encoder.down_blocks." + std::to_string(i) + ".";

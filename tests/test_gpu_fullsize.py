@@ -140,13 +140,18 @@ def test_vae_sd15_512px():
     ref = R.AutoencoderKLEncoder(R.VAE_SD15)
     ref.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
     ref.eval()
-    a, _ = S.make_image_pair(0, 512)
+    a, b = S.make_image_pair(0, 512)
     with torch.no_grad():
         want = ref.moments(a)
-    got = VAEEncoder(cfg, sd, torch.float32).moments(a).cpu()
+    enc32 = VAEEncoder(cfg, sd, torch.float32)
+    got = enc32.moments(a).cpu()
     assert got.shape == want.shape == (1, 8, 64, 64)
     err = (got - want).abs().max().item()
     assert err <= 2e-4 * max(float(want.abs().max()), 1.0), err
+    # two images: the mid attention's q k^T and P v run as ONE launch each with per-image weights (GemmArgs.wb_rows)
+    got2 = enc32.moments(torch.cat([b, a])).cpu()
+    err2 = (got2[1:] - want).abs().max().item()
+    assert err2 <= 2e-4 * max(float(want.abs().max()), 1.0), err2
     gotb = VAEEncoder(cfg, sd, torch.bfloat16).moments(a).cpu()
     errb = (gotb - want).abs().max().item()
     assert errb <= 6e-2 * max(float(want.abs().max()), 1.0), errb

@@ -205,7 +205,9 @@ constexpr int gemm_spare_bytes() {
 // (the wave's own BN / WN columns) together with the tile's first K stage; f32: two slices of BN columns filled through registers.
 template <typename T, int BM, int BN, bool GEGLU, int WM, int WN>
 constexpr int gemm_lds_bytes() {
-    return 2 * (BM + BN) * 128 + gemm_spare_bytes<T, BM, BN, GEGLU, WM, WN>() + (sizeof(T) == 2 ? 2 * WM * WN * 1024 : 2 * BN * 4);
+    // (512-row tiles: the two stages ARE the 160 KB; their bias comes straight from global memory into the accumulators)
+    return 2 * (BM + BN) * 128 + gemm_spare_bytes<T, BM, BN, GEGLU, WM, WN>() +
+           (BM >= 512 ? 0 : (sizeof(T) == 2 ? 2 * WM * WN * 1024 : 2 * BN * 4));
 }
 
 // WM x WN waves; each owns a (BM/WM) x (BN/WN) sub-tile of 16 x 16 accumulator tiles, so an activation fragment is reused by
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     // 16-bit kernels: the f32 bias of the wave's own BN / WN columns arrives by one LDS-DMA piece per wave and tile (issued with the
     // tile's first K stage, i.e. a whole epilogue ahead; columns beyond N read as zeros through the descriptor's range check, as
     // does everything when there is no bias).  The per-CFG-half bias2 of SDXL's resnets keeps the register path.
-    constexpr bool BDMA = sizeof(T) == 2;
+    constexpr bool BDMA = sizeof(T) == 2 && BM < 512;
     static_assert(!BDMA || (BN / WN) * 4 <= 1024, "bias slot");
     const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc((void*)(p.bias ? (const void*)p.bias : p.W), 0, p.bias ? p.N * 4 : 0, 0x00020000);
     auto bias_dma = [&](int par) {       // slice of the tile setup() last ran for, into the slot of tile parity `par`
@@ -378,11 +380,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
             second = k0 >= p.C0;
             soff = (second ? k0 - p.C0 : k0) * (int)sizeof(T);
         }
+#ifdef DSIM_DEVTOOLS
+        // kbench ablation (timing only): KB_GEXP bit 64 = the activation pieces of two tap columns out of three are not issued -- the
+        // DMA count of a conv whose three horizontal taps share one staged row block; bit 128 = none of them after the first K tile
+        const bool skipA = CONV && (((p.exp & 64) && (k0 / p.C0) % 3 != 0) || ((p.exp & 128) && t > 0));
+#else
+        constexpr bool skipA = false;
+#endif
+        if (!skipA) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             auto lds = (__attribute__((address_space(3))) void*)(sa + (i * NW + DMAW) * 1024);
             if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, lds, 16, (int)a_voff[i], soff, 0, 0);
             else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, lds, 16, (int)a_voff[i], soff, 0, 0);
+        }
         }
         const int soffw = k0 * (int)sizeof(T);
 #pragma unroll
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     constexpr bool ACT = EK == EK_ACT;
     // linear layers start their accumulators at the bias (see the tile loop); the 3x3 conv keeps the bias add in its epilogue
     // (its K loop is long enough that the epilogue's loads do not matter, and the changed register allocation cost it 2.5 %)
-    constexpr bool BIAS_INIT = !CONV;
+    constexpr bool BIAS_INIT = !CONV || BM >= 512;
     const bool has_res = EK == EK_RES || (SLOW && p.epi == EPI_RESIDUAL);
 
     STAMP_DECL;
@@ -1021,6 +1032,10 @@ int launch_typed(const GemmArgs& a_in, hipStream_t s) {
                 return bn == 320 ? launch_one<T, 256, 320, GEMM_LINEAR, true, 4, 2>(a, s) : launch_one<T, 256, 256, GEMM_LINEAR, true, 4, 2>(a, s);
             if (a.mode == GEMM_CONV3) {
                 // (the VAE's 128-channel levels: power-of-two maps as well -- setup()'s integer divisions were 10 % of these K = 1152 tiles)
+#ifdef DSIM_DEVTOOLS
+                if (bn == 128 && a.lwo >= 0 && g_force_bm == 512 && a.epi != EPI_RESIDUAL && !a.gn_part && !a.bias2)
+                    return launch_ek<T, 512, 128, GEMM_CONV3P, false, 8, 1, EK_PLAIN>(a, s);
+#endif
                 if (bn == 128) return a.lwo >= 0 ? launch_one<T, 256, 128, GEMM_CONV3P, false, 4, 2>(a, s)
                                                  : launch_one<T, 256, 128, GEMM_CONV3, false, 4, 2>(a, s);
                 // power-of-two output maps (every SD level at the sizes these tiles serve): the instantiation without the integer

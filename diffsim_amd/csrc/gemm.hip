@@ -555,8 +555,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
                 mma_piece(q);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef DSIM_DEVTOOLS
+            // kbench ablations (timing only): KB_GEXP bit 256 = no barrier at the end of a K tile, 512 = no wait for the staged pieces either
+            if (!(p.exp & 512)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(p.exp & 256)) __syncthreads(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                    // (also drains this wave's fragment reads of `cur`)
+#endif
             if (t + 1 < nk) { load_x(cur ^ 1, 0, 0); load_w(cur ^ 1, 0, 0); }
             __builtin_amdgcn_sched_barrier(0);
             mma_piece(2 * NP - 1);                              // the tile's last piece, from registers

@@ -193,7 +193,7 @@ inline bool gemm_gn_stats_tile(const GemmArgs& a, int dtype) {
     if (gemm_skinny_applies(a)) return false;
     int bm, bn;
     gemm_launch_tile(a, dtype, &bm, &bn);
-    return bm == 256 && (bn == 128 || bn == 256) && a.N % bn == 0;
+    return ((bm == 256 && (bn == 128 || bn == 256)) || (bm == 512 && bn == 128)) && a.N % bn == 0 && hw % bm == 0;
 }
 
 // weight repack kernels -- pack.hip  (src f32/h16/f16 diffusers layout -> packed compute dtype)

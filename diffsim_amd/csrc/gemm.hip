@@ -116,6 +116,14 @@ void gemm_launch_tile(const GemmArgs& a, int dtype, int* bm, int* bn) {
     gemm_tile_choice(a, bm, bn);
     const bool slow = a.act != 0 || a.gate != nullptr;
     const bool act_only = a.act == 1 && !a.gate && a.epi != EPI_RESIDUAL;
+    // N = 128 convs, 16-bit: 512-row tiles (8 waves as 8 x 1, 64 x 128 per wave: 0.375 instead of 0.5 KB of fragment reads per MFMA; -6 % at
+    // 512 x 512 x 128, profiles/r05_experiments.txt item 9) where ONE image alone makes >= 256 of them on a power-of-two map -- so the
+    // choice, and with it every partial sum of the epilogue statistics, is the same at every batch size
+    if (*bm == 256 && *bn == 128 && dtype != DSIM_F32 && a.mode == GEMM_CONV3 && !a.bias2 && g_force_bm != 256) {
+        const long hw = (long)a.Hout * a.Wout;
+        if (hw >= 512L * 256 && !(hw & (hw - 1)) && a.Wout > 0 && !(a.Wout & (a.Wout - 1)) && a.M % hw == 0) *bm = 512;
+    }
+    if (*bm == 512) return;
     bool big = *bm == 256 && dtype != DSIM_F32;
     if (big && slow && *bn == 320 && !act_only) big = false;
     if (!big) {
@@ -962,7 +970,7 @@ int launch_one(const GemmArgs& a, hipStream_t s) {
         if (a.act == 1 && !a.gate && a.epi != EPI_RESIDUAL) return launch_ek<T, BM, BN, MODE, GEGLU, WM, WN, EK_ACT>(a, s);
         return launch_ek<T, BM, BN, MODE, GEGLU, WM, WN, EK_SLOW>(a, s);
     }
-    if constexpr (!GEGLU && sizeof(T) == 2 && MODE == GEMM_CONV3P && BM == 256 && (BN == 128 || BN == 256)) {
+    if constexpr (!GEGLU && sizeof(T) == 2 && MODE == GEMM_CONV3P && ((BM == 256 && (BN == 128 || BN == 256)) || (BM == 512 && BN == 128))) {
         // GroupNorm statistics from the epilogue (GemmArgs.gn_part): the VAE's 512 x 512 / 256 x 256 levels on their 256-row tiles
         if (a.gn_part) {
             if (a.gn_hw <= 0 || a.gn_hw % BM || a.M % a.gn_hw || a.N % BN || a.bias2) return DSIM_ERR_INVALID;
@@ -1029,6 +1037,8 @@ int launch_typed(const GemmArgs& a_in, hipStream_t s) {
     // out_split: the epilogue picks ONE destination tensor per tile from its first column, so the tile width must divide the split
     if (a.out_split && a.out_split % bn != 0) return DSIM_ERR_INVALID;
     if (a.wb_rows % bm != 0) return DSIM_ERR_INVALID;           // a tile's rows belong to one weight batch
+    if constexpr (sizeof(T) == 2)
+        if (bm == 512) return a.lwo >= 0 && bn == 128 ? launch_one<T, 512, 128, GEMM_CONV3P, false, 8, 1>(a, s) : DSIM_ERR_INVALID;
     const bool big = bm == 256, n160 = bn == 160;
     (void)big;
     if constexpr (sizeof(T) == 2) {
@@ -1038,10 +1048,6 @@ int launch_typed(const GemmArgs& a_in, hipStream_t s) {
                 return bn == 320 ? launch_one<T, 256, 320, GEMM_LINEAR, true, 4, 2>(a, s) : launch_one<T, 256, 256, GEMM_LINEAR, true, 4, 2>(a, s);
             if (a.mode == GEMM_CONV3) {
                 // (the VAE's 128-channel levels: power-of-two maps as well -- setup()'s integer divisions were 10 % of these K = 1152 tiles)
-#ifdef DSIM_DEVTOOLS
-                if (bn == 128 && a.lwo >= 0 && g_force_bm == 512 && a.epi != EPI_RESIDUAL && !a.gn_part && !a.bias2)
-                    return launch_ek<T, 512, 128, GEMM_CONV3P, false, 8, 1, EK_PLAIN>(a, s);
-#endif
                 if (bn == 128) return a.lwo >= 0 ? launch_one<T, 256, 128, GEMM_CONV3P, false, 4, 2>(a, s)
                                                  : launch_one<T, 256, 128, GEMM_CONV3, false, 4, 2>(a, s);
                 // power-of-two output maps (every SD level at the sizes these tiles serve): the instantiation without the integer

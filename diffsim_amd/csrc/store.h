@@ -105,7 +105,7 @@ static inline std::string gemm_family(const GemmArgs& g, int dt, double* flops, 
     const bool skinny = dt != DSIM_F32 && !(g.wb_rows && g.wb_rows != g.M) && gemm_skinny_applies(g);      // the small-batch kernel (gemm_skinny.hip)
     // 256-row 16-bit conv tiles on power-of-two output maps run the CONV3P instantiation (gemm.hip launch_typed)
     const int hwo = g.Hout * g.Wout;
-    const bool conv_p2 = g.mode == GEMM_CONV3 && !skinny && dt != DSIM_F32 && bm == 256 && g.Wout > 0 &&
+    const bool conv_p2 = g.mode == GEMM_CONV3 && !skinny && dt != DSIM_F32 && (bm == 256 || bm == 512) && g.Wout > 0 &&
                          !(g.Wout & (g.Wout - 1)) && !(hwo & (hwo - 1));
     if (skinny) gemm_skinny_tile(g, &bm, &bn);
     const char* dtn = dt == DSIM_F32 ? "f32" : (dt == DSIM_F16 ? "f16" : "bf16");

@@ -296,6 +296,29 @@ def test_attention_fp8(eng, B, Bkv, H, Nq, Nk, D):
     assert float((got16 - want).abs().max()) < float(err.max())            # the bf16 kernel is the accurate one
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv3x3_vae_512px_level_on_512_row_tiles(eng, dtype):
+    """The VAE's 128 -> 128 channel 3x3 conv at 512 x 512 (16-bit: 512 x 128 tiles, 8 waves as 8 x 1; bias goes straight into the
+    accumulators there), plain and with a residual; checked on the image borders, the tile seams and the second image."""
+    B, H, W, Cin, Cout = 2, 512, 512, 128, 128
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(B, H, W, Cout, generator=g)
+    xd, rd = _dev(x, dtype), _dev(r, dtype)
+    plain = eng.op_conv3x3(xd, _dev(w), _dev(b)).float().cpu()
+    res = eng.op_conv3x3(xd, _dev(w), _dev(b), rd).float().cpu()
+    assert torch.isfinite(plain).all() and torch.isfinite(res).all()
+    rows = [0, 1, 2, 255, 256, 510, 511]                     # image rows (a 512-row tile = one image row)
+    want = F.conv2d(_q(x, dtype).permute(0, 3, 1, 2), _q(w, dtype), b, padding=1).permute(0, 2, 3, 1)
+    _close(plain[:, rows], want[:, rows], dtype)
+    _close(res[:, rows], (want + _q(r, dtype))[:, rows], dtype)
+    # the same bits whatever the batch: one image alone takes the same tiles
+    one = eng.op_conv3x3(xd[1:].contiguous(), _dev(w), _dev(b), rd[1:].contiguous()).float().cpu()
+    assert torch.equal(one[0], res[1])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv3x3_vae_width_many_tiles(eng, dtype):
     """The VAE's 128 -> 128 channel 3x3 conv on a large map (bf16: 256x128 tiles, 320 of them)."""

@@ -107,7 +107,6 @@ static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H,
     for (int v = 0; v < 3; ++v) {
         g_force_bm = forces[v];
         g_gemm_persistent = 1;
-        if (getenv("KB_FORCE512") && (v == 0 || atoi(getenv("KB_FORCE512")) == 2)) g_force_bm = 512;                             // column 1 = the 512 x 128 conv tile where it exists
         if (v == 0 && getenv("KB_NOPERSIST")) { g_force_bm = 0; g_gemm_persistent = 0; }   // column 1 = auto tiles, one tile per workgroup
         msv[v] = t.run([&] { st = launch_gemm(g, DSIM_BF16, 0); }, iters);
     }
@@ -179,7 +178,7 @@ static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H,
         unsigned long long* sb;
         HC(hipMalloc((void**)&sb, 64));
         HC(hipMemset(sb, 0, 64));
-        g_force_bm = getenv("KB_FORCE512") ? 512 : 0; g_gemm_stamps = sb;
+        g_force_bm = 0; g_gemm_stamps = sb;
         st = launch_gemm(g, DSIM_BF16, 0);
         HC(hipDeviceSynchronize());
         g_gemm_stamps = nullptr;

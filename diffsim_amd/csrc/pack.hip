@@ -253,80 +253,101 @@ __global__ __launch_bounds__(256) void prep_conv_in8_kernel(const float* __restr
 }
 
 // The VAE's conv_in: 3 -> 128 channels at the full image resolution (512 x 512: 67 MB of output per image; the direct kernels above
-// spend their time on per-element index arithmetic and on 2 weight loads per 32 FMAs and reach 1.4 TB/s of it).  A workgroup takes 64
-// consecutive pixels of one image row; a thread owns ONE 4-channel quad (its 27 x 4 weights live in registers for the whole
-// workgroup) and 8 consecutive pixels, whose 3 x 3 x 10 input window it reads once from the staged rows -- the inner loop is FMAs only.
+// spend their time on per-element index arithmetic and on 2 weight loads per 32 FMAs and reach 1.4 TB/s of it).  A workgroup walks up
+// to eight 64-pixel segments of one image row; a thread owns ONE 4-channel quad (its 27 x 4 weights are loaded once and live in
+// registers) and 8 consecutive pixels of each segment, whose 3 x 3 x 10 input window it reads once from the staged rows -- the inner
+// loop is FMAs only --, and the next segment's input values are in flight under the current segment's FMAs (one segment per
+// workgroup was latency-bound: two resident workgroups per CU each waiting out a global and an L2 round trip before 0.9 us of math).
 // Same bias-first, ascending-k fmaf chain per output as prep_conv_in_kernel: bit-identical.  STATS: the consumer's GroupNorm
 // statistics in the conv epilogue's format (launch_groupnorm_pre: per (64-pixel chunk, 4-channel quad) f32 sum and sum of squares of
-// the STORED values, a fixed order: pixels of a thread, the wave's two halves, the four waves) -- the workgroup IS one chunk.
+// the STORED values, a fixed order: pixels of a thread, the wave's two halves, the four waves) -- a segment IS one chunk.
 template <typename T, bool STATS>
 __global__ __launch_bounds__(256) void conv_in_rows_kernel(const float* __restrict__ img, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, T* __restrict__ out, int S,
+                                                           const float* __restrict__ bias, T* __restrict__ out, int S, int nseg,
                                                            float* __restrict__ gn_part) {
     constexpr int CIN = 3, COUT = 128, PX = 64, PW = PX + 2, PT = 8, K = 9 * CIN;
-    __shared__ float patch[CIN * 3][PW + 2];
-    __shared__ float s_st[4][32][2];
+    constexpr int NPF = (CIN * 3 * PW + 255) / 256;             // staged input values per thread and segment (3)
+    __shared__ float patch[2][CIN * 3][PW + 2];
+    __shared__ float s_st[2][4][32][2];
     const int tid = threadIdx.x, cg = tid & 31, pl = tid >> 5;
-    const int xb = blockIdx.x * PX, y = blockIdx.y, im = blockIdx.z;
-    for (int i = tid; i < CIN * 3 * PW; i += 256) {
-        const int r = i / PW, xx = i - r * PW;
-        const int ci = r / 3, dy = r - ci * 3;
-        const int yy = y + dy - 1, x = xb + xx - 1;
-        float v = 0.f;
-        if ((unsigned)yy < (unsigned)S && (unsigned)x < (unsigned)S) v = img[((size_t)(im * CIN + ci) * S + yy) * S + x];
-        patch[r][xx] = v;
+    const int y = blockIdx.y, im = blockIdx.z, seg0 = blockIdx.x * nseg;
+    // the staged window of a segment: value i of the [ci * 3 + dy][66] block (a thread owns i = tid + 256 j); fetched one segment ahead
+    int pr[NPF], pxx[NPF];
+    const float* prow[NPF];
+#pragma unroll
+    for (int j = 0; j < NPF; ++j) {
+        const int i = tid + 256 * j, r = i / PW;
+        pr[j] = r; pxx[j] = i - r * PW;
+        const int ci = r / 3, dy = r - ci * 3, yy = y + dy - 1;
+        prow[j] = (i < CIN * 3 * PW && (unsigned)yy < (unsigned)S) ? img + ((size_t)(im * CIN + ci) * S + yy) * S : nullptr;
     }
+    float pf[NPF];
+    auto fetch = [&](int seg) {
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int x = seg * PX + pxx[j] - 1;
+            pf[j] = (prow[j] && (unsigned)x < (unsigned)S) ? prow[j][x] : 0.f;
+        }
+    };
+    fetch(seg0);
     f32x4 wr[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) wr[k] = *reinterpret_cast<const f32x4*>(w + k * COUT + cg * 4);
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + cg * 4);
-    __syncthreads();
-    float pv[CIN * 3][PT + 2];
-#pragma unroll
-    for (int r = 0; r < CIN * 3; ++r)
-#pragma unroll
-        for (int j = 0; j < PT + 2; ++j) pv[r][j] = patch[r][pl * PT + j];
-    // (two-wide vectors: v_pk_fma_f32, two FMAs per lane and issue slot -- the loop is FMA-issue bound)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 acc[PT][2];
+    for (int s = 0; s < nseg; ++s) {
+        const int seg = seg0 + s, buf = s & 1, xb = seg * PX;
 #pragma unroll
-    for (int p = 0; p < PT; ++p) { acc[p][0] = f32x2{bv[0], bv[1]}; acc[p][1] = f32x2{bv[2], bv[3]}; }
+        for (int j = 0; j < NPF; ++j)
+            if (tid + 256 * j < CIN * 3 * PW) patch[buf][pr[j]][pxx[j]] = pf[j];
+        __syncthreads();                                        // (also: everybody is done with buffer `buf` of two segments ago)
+        if (s + 1 < nseg) fetch(seg + 1);                       // in flight under this segment's FMAs
+        float pv[CIN * 3][PT + 2];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+        for (int r = 0; r < CIN * 3; ++r)
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) {
-            const int k = tap * CIN + ci, r = ci * 3 + tap / 3, dx = tap % 3;
-            const f32x2 w0 = {wr[k][0], wr[k][1]}, w1 = {wr[k][2], wr[k][3]};
+            for (int j = 0; j < PT + 2; ++j) pv[r][j] = patch[buf][r][pl * PT + j];
+        // (two-wide vectors: v_pk_fma_f32, two FMAs per lane and issue slot)
+        f32x2 acc[PT][2];
 #pragma unroll
-            for (int p = 0; p < PT; ++p) {
-                const f32x2 a = {pv[r][p + dx], pv[r][p + dx]};
-                acc[p][0] = __builtin_elementwise_fma(a, w0, acc[p][0]);
-                acc[p][1] = __builtin_elementwise_fma(a, w1, acc[p][1]);
+        for (int p = 0; p < PT; ++p) { acc[p][0] = f32x2{bv[0], bv[1]}; acc[p][1] = f32x2{bv[2], bv[3]}; }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                const int k = tap * CIN + ci, r = ci * 3 + tap / 3, dx = tap % 3;
+                const f32x2 w0 = {wr[k][0], wr[k][1]}, w1 = {wr[k][2], wr[k][3]};
+#pragma unroll
+                for (int p = 0; p < PT; ++p) {
+                    const f32x2 a = {pv[r][p + dx], pv[r][p + dx]};
+                    acc[p][0] = __builtin_elementwise_fma(a, w0, acc[p][0]);
+                    acc[p][1] = __builtin_elementwise_fma(a, w1, acc[p][1]);
+                }
             }
-        }
-    T* o = out + ((size_t)im * S * S + (size_t)y * S + xb + pl * PT) * COUT + cg * 4;
-    float ss = 0.f, qq = 0.f;
+        T* o = out + ((size_t)im * S * S + (size_t)y * S + xb + pl * PT) * COUT + cg * 4;
+        float ss = 0.f, qq = 0.f;
 #pragma unroll
-    for (int p = 0; p < PT; ++p) {
-        typedef T Tx4 __attribute__((ext_vector_type(4)));
-        Tx4 v;
+        for (int p = 0; p < PT; ++p) {
+            typedef T Tx4 __attribute__((ext_vector_type(4)));
+            Tx4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e] = (T)acc[p][e >> 1][e & 1];
-            if (STATS) { const float r = (float)v[e]; ss += r; qq = fmaf(r, r, qq); }
+            for (int e = 0; e < 4; ++e) {
+                v[e] = (T)acc[p][e >> 1][e & 1];
+                if (STATS) { const float r = (float)v[e]; ss += r; qq = fmaf(r, r, qq); }
+            }
+            *reinterpret_cast<Tx4*>(o + (size_t)p * COUT) = v;
         }
-        *reinterpret_cast<Tx4*>(o + (size_t)p * COUT) = v;
-    }
-    if constexpr (STATS) {
-        ss += __shfl_xor(ss, 32, 64);
-        qq += __shfl_xor(qq, 32, 64);
-        if ((tid & 63) < 32) { s_st[tid >> 6][cg][0] = ss; s_st[tid >> 6][cg][1] = qq; }
-        __syncthreads();
-        if (tid < 32) {
-            const float a = ((s_st[0][cg][0] + s_st[1][cg][0]) + s_st[2][cg][0]) + s_st[3][cg][0];
-            const float q = ((s_st[0][cg][1] + s_st[1][cg][1]) + s_st[2][cg][1]) + s_st[3][cg][1];
-            const size_t chunk = (size_t)im * (S * S / PX) + ((size_t)y * S + xb) / PX;
-            *reinterpret_cast<float2*>(gn_part + (chunk * (COUT / 4) + cg) * 2) = make_float2(a, q);
+        if constexpr (STATS) {
+            ss += __shfl_xor(ss, 32, 64);
+            qq += __shfl_xor(qq, 32, 64);
+            if ((tid & 63) < 32) { s_st[buf][tid >> 6][cg][0] = ss; s_st[buf][tid >> 6][cg][1] = qq; }
+            __syncthreads();
+            if (tid < 32) {
+                const float a = ((s_st[buf][0][cg][0] + s_st[buf][1][cg][0]) + s_st[buf][2][cg][0]) + s_st[buf][3][cg][0];
+                const float q = ((s_st[buf][0][cg][1] + s_st[buf][1][cg][1]) + s_st[buf][2][cg][1]) + s_st[buf][3][cg][1];
+                const size_t chunk = (size_t)im * (S * S / PX) + ((size_t)y * S + xb) / PX;
+                *reinterpret_cast<float2*>(gn_part + (chunk * (COUT / 4) + cg) * 2) = make_float2(a, q);
+            }
         }
     }
 }
@@ -387,15 +408,17 @@ bool conv_in_rows_applies(int Cin, int S, int Cout) { return Cin == 3 && Cout ==
 int conv_in_rows(const float* images, const float* w, const float* bias, void* out, int dtype, int n_img, int S, float* gn_part,
                  hipStream_t st) {
     if (n_img < 1 || n_img > 65535 || (gn_part && dtype == DSIM_F32)) return DSIM_ERR_INVALID;
-    const dim3 grid(S / 64, S, n_img);
+    int nseg = 8;                                         // 64-pixel segments of an image row one workgroup walks (weights loaded once)
+    while ((S / 64) % nseg) nseg >>= 1;
+    const dim3 grid(S / 64 / nseg, S, n_img);
     if (dtype == DSIM_BF16) {
-        if (gn_part) hipLaunchKernelGGL((conv_in_rows_kernel<bf16_t, true>), grid, dim3(256), 0, st, images, w, bias, (bf16_t*)out, S, gn_part);
-        else hipLaunchKernelGGL((conv_in_rows_kernel<bf16_t, false>), grid, dim3(256), 0, st, images, w, bias, (bf16_t*)out, S, gn_part);
+        if (gn_part) hipLaunchKernelGGL((conv_in_rows_kernel<bf16_t, true>), grid, dim3(256), 0, st, images, w, bias, (bf16_t*)out, S, nseg, gn_part);
+        else hipLaunchKernelGGL((conv_in_rows_kernel<bf16_t, false>), grid, dim3(256), 0, st, images, w, bias, (bf16_t*)out, S, nseg, gn_part);
     } else if (dtype == DSIM_F16) {
-        if (gn_part) hipLaunchKernelGGL((conv_in_rows_kernel<f16_t, true>), grid, dim3(256), 0, st, images, w, bias, (f16_t*)out, S, gn_part);
-        else hipLaunchKernelGGL((conv_in_rows_kernel<f16_t, false>), grid, dim3(256), 0, st, images, w, bias, (f16_t*)out, S, gn_part);
+        if (gn_part) hipLaunchKernelGGL((conv_in_rows_kernel<f16_t, true>), grid, dim3(256), 0, st, images, w, bias, (f16_t*)out, S, nseg, gn_part);
+        else hipLaunchKernelGGL((conv_in_rows_kernel<f16_t, false>), grid, dim3(256), 0, st, images, w, bias, (f16_t*)out, S, nseg, gn_part);
     } else if (dtype == DSIM_F32) {
-        hipLaunchKernelGGL((conv_in_rows_kernel<float, false>), grid, dim3(256), 0, st, images, w, bias, (float*)out, S, gn_part);
+        hipLaunchKernelGGL((conv_in_rows_kernel<float, false>), grid, dim3(256), 0, st, images, w, bias, (float*)out, S, nseg, gn_part);
     } else {
         return DSIM_ERR_INVALID;
     }

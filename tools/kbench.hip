@@ -308,6 +308,15 @@ static void bench_gn(const char* name, int B, int HW, int C, int iters, Timer& t
     HC(hipMalloc(&sc, groupnorm_scratch_bytes(B, 32)));
     int st = DSIM_OK;
     const float ms = t.run([&] { st = launch_groupnorm(x, C, nullptr, 0, g, b, out, B, HW, 32, 1e-5f, 1, DSIM_BF16, sc, 0); }, iters);
+    if (getenv("KB_GN_SILU")) {      // with and without the SiLU, interleaved: is the apply pass VALU-limited?
+        std::vector<float> a, c;
+        for (int r = 0; r < 5; ++r) {
+            a.push_back(t.run([&] { st = launch_groupnorm(x, C, nullptr, 0, g, b, out, B, HW, 32, 1e-5f, 1, DSIM_BF16, sc, 0); }, iters));
+            c.push_back(t.run([&] { st = launch_groupnorm(x, C, nullptr, 0, g, b, out, B, HW, 32, 1e-5f, 0, DSIM_BF16, sc, 0); }, iters));
+        }
+        std::sort(a.begin(), a.end()); std::sort(c.begin(), c.end());
+        printf("  median ms with SiLU %.3f, without %.3f\n", a[2], c[2]);
+    }
     const double by = 3.0 * B * (double)HW * C * 2;
     printf("%-28s B=%3d HW=%5d C=%5d                 %8.3f ms  %7.1f GB/s  st=%d\n", name, B, HW, C, ms, by / ms / 1e6, st);
     if (getenv("KB_GNCHUNK")) {      // statistics + apply per sub-batch of images (does the apply pass then read from the Infinity Cache?)

@@ -56,6 +56,7 @@ class DiTCfgC(C.Structure):
 
 # every symbol include/diffsim_amd.h declares: (restype, argtypes)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+ABI_VERSION = 7          # include/diffsim_amd.h DSIM_ABI_VERSION (tests/test_host.py checks the header against it)
 SYMBOLS = {
     "dsim_version": (_i, []),
     "dsim_strerror": (C.c_char_p, [_i]),
@@ -129,8 +130,8 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.dsim_version() != 7:
-            raise DsimError("ABI version mismatch")
+        if L.dsim_version() != ABI_VERSION:
+            raise DsimError(f"ABI version mismatch: library {L.dsim_version()}, bindings {ABI_VERSION}")
         _lib = L
     return _lib
 

@@ -29,7 +29,10 @@ def test_abi_exports_every_declared_symbol(lib):
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.dsim_version() == 7
+    hv = int(re.search(r"#define\s+DSIM_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.dsim_version() == hv == _lib.ABI_VERSION == 7            # header, library and bindings agree
+    # ... and so does the driver's build check (it broke once on a literal)
+    assert "_lib.ABI_VERSION" in open(os.path.join(ROOT, "__graft_entry__.py")).read()
     assert lib.dsim_strerror(0) == b"ok"
     assert b"workspace" in lib.dsim_strerror(-3)
 

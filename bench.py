@@ -54,8 +54,12 @@ def rocprof_name(fam: str) -> str:
         mode = {"conv3": "1", "conv3p": "2"}.get(p[3], "0")      # conv3p: the instantiation for power-of-two output maps
         geglu = "true" if fam.endswith("_geglu") else "false"
         wm, wn = ("8", "1") if bm == "512" else ("4", "2" if bm == "256" else "1")      # 512-row tiles: 8 x 1 waves; 256: 4 x 2; 128: 4 x 1
-        # epilogue kind: plain / residual / DiT gate(+act, +residual) / DiT tanh-GELU only
-        ek = "1" if fam.endswith("_res") else ("2" if fam.endswith("_dit") else ("3" if fam.endswith("_act") else "0"))
+        # epilogue kind: plain / residual / DiT gate(+act, +residual) / DiT tanh-GELU only; + 4 with GroupNorm statistics (_gn)
+        gn = fam.endswith("_gn")
+        base = fam[:-3] if gn else fam
+        ek = "1" if base.endswith("_res") else ("2" if base.endswith("_dit") else ("3" if base.endswith("_act") else "0"))
+        if gn:
+            ek = str(int(ek) + 4)
         return f"gemm_kernel<{t}, {bm}, {bn}, {mode}, {geglu}, {wm}, {wn}, {ek}>"
     if p[0] == "attention":
         if p[1] == "fp8":

@@ -116,7 +116,7 @@ static inline std::string gemm_family(const GemmArgs& g, int dt, double* flops, 
                   (double)g.M * outc * (g.residual ? 2 : 1));
     return std::string(skinny ? "gemm_small_" : "gemm_") + dtn + "_" + std::to_string(bm) + "x" + std::to_string(bn) +
            (g.mode == GEMM_CONV3 ? (conv_p2 ? "_conv3p" : "_conv3") : "_linear") +
-           (g.epi == EPI_GEGLU ? "_geglu" : (g.epi == EPI_RESIDUAL ? "_res" : "")) +
+           (g.epi == EPI_GEGLU ? "_geglu" : (g.epi == EPI_RESIDUAL ? "_res" : "")) + (g.gn_part ? "_gn" : "") +      // _gn: the statistics epilogue kinds
            "|M" + std::to_string(g.M) + " N" + std::to_string(g.N) + " K" + std::to_string(g.K);
 }
 

@@ -150,6 +150,14 @@ def test_bench_kernel_names_match_the_committed_rocprof_summaries():
         assert name in mfma and name in hbm, (fam, name)
     assert line["roofline"]["kernel"] in stats
     assert bench.pmc_traffic(line["roofline"]["kernel"]) and bench.pmc_mfma_util(line["roofline"]["kernel"])
+    # ... and the VAE families of the same snapshot's --pixels-in line (among them the 512 x 128 conv tiles, 8 x 1 waves) in its kernel trace
+    px, pstats = (os.path.join(root, "profiles", f"{tag}_{n}") for n in ("bench_pixels_in.json", "pixels_in_kernel_stats.csv"))
+    if os.path.exists(px) and os.path.exists(pstats):
+        pk = {r["kernel"] for r in csv.DictReader(open(pstats))}
+        vfams = [k for k in json.load(open(px))["kernel_breakdown_ms_per_step"] if k.startswith("vae_gemm_")]
+        assert vfams
+        for fam in vfams:
+            assert bench.rocprof_name(fam) in pk, (fam, bench.rocprof_name(fam))
 
 
 def test_bench_pmc_fields_come_from_the_pass_of_the_same_model():

@@ -20,6 +20,8 @@
 
 using namespace dsim;
 
+constexpr int VAE_VREP = 16;          // copies of the mid-block attention's to_v weight (finalize): images per batched v^T launch
+
 struct dsim_vae : WeightStore {
     dsim_vae_cfg cfg;
 };
@@ -214,8 +216,16 @@ struct VWalk {
         const size_t img = (size_t)N * C * es();
         for (int i0 = 0; i0 < n; i0 += grp) {
             const int gi = std::min(grp, n - i0);
-            for (int i = 0; i < gi; ++i)
-                CK(linear(wv->p, C, t + (i0 + i) * img, nullptr, nullptr, vT + i * img, C, N));       // v^T = Wv x^T
+            const Packed* wrep = h->find(p + "to_v.weight_rep");
+            for (int i = 0; i < gi;) {                                                                // v^T = Wv x^T
+                const int nb = (wrep && C % 256 == 0) ? std::min(gi - i, VAE_VREP) : 1;
+                GemmArgs gv;
+                gv.A0 = nb > 1 ? wrep->p : wv->p; gv.C0 = C; gv.mode = GEMM_LINEAR; gv.M = nb * C; gv.N = N; gv.K = C;
+                gv.W = t + (i0 + i) * img; gv.epi = EPI_NONE; gv.out = vT + i * img; gv.ldo = N;
+                if (nb > 1) { gv.wb_rows = C; gv.wb_stride = (unsigned)img; }
+                CK(gemm(gv));
+                i += nb;
+            }
             GemmArgs g;
             g.A0 = q + i0 * img; g.C0 = C; g.mode = GEMM_LINEAR; g.M = gi * N; g.N = N; g.K = C; g.W = k + i0 * img;
             g.epi = EPI_NONE; g.out = sc; g.ldo = N; g.wb_rows = N; g.wb_stride = (unsigned)img;
@@ -374,6 +384,17 @@ int dsim_vae_finalize(dsim_vae* h, void* stream) {
     DSIM_HIP_CHECK(hipGetLastError());
     h->pk["encoder.conv_out_folded.weight"] = fw;
     h->pk["encoder.conv_out_folded.bias"] = fb;
+    // the mid-block attention's to_v weight, VAE_VREP copies back to back: v^T = Wv x^T of a whole group of images is then ONE launch
+    // whose row block i (= copy i of Wv) multiplies image i's tokens (GemmArgs.wb_rows)
+    if (const Packed* wv = h->find("encoder.mid_block.attentions.0.to_v.weight")) {
+        const size_t one = (size_t)wv->rows * wv->cols * dtype_size(h->dt);
+        Packed rep;
+        rep.rows = wv->rows * VAE_VREP; rep.cols = wv->cols;
+        CK(h->dalloc(one * VAE_VREP, &rep.p));
+        for (int i = 0; i < VAE_VREP; ++i)
+            DSIM_HIP_CHECK(hipMemcpyAsync((char*)rep.p + i * one, wv->p, one, hipMemcpyDeviceToDevice, s));
+        h->pk["encoder.mid_block.attentions.0.to_v.weight_rep"] = rep;
+    }
     DSIM_HIP_CHECK(hipStreamSynchronize(s));
     h->raw.clear();
     h->finalized = true;

@@ -545,5 +545,8 @@ int main(int argc, char** argv) {
     bench_gn("gn_64_320", B2, 4096, 320, iters, t);
     bench_gn("gn_32_640", B2, 1024, 640, iters, t);
     bench_gn("gn_16_1280", B2, 256, 1280, iters, t);
+    bench_gn("gn_vae512_128", std::max(1, B2 / 16), 512 * 512, 128, iters, t);       // the VAE's levels (B2 / 16 images)
+    bench_gn("gn_vae256_256", std::max(1, B2 / 16), 256 * 256, 256, iters, t);
+    bench_gn("gn_vae128_512", std::max(1, B2 / 16), 128 * 128, 512, iters, t);
     return 0;
 }

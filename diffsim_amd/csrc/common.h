@@ -136,6 +136,8 @@ struct GemmArgs {
     int ldo = 0;
     int out_split = 0;                          // > 0 (plain linear only, % 320 == 0): output columns [j*split, (j+1)*split) go to the
     long long out_split_stride = 0;             //   tensor at out + j * out_split_stride bytes, each [M][ldo] (the tapped q | k | v)
+    int force_big = 0;                          // 1: 256-row tiles whatever the tile count (a caller that needs the SAME tiles at every batch size:
+                                                //    the VAE's 128 x 128 level asks for epilogue statistics, whose partial sums follow the tile shape)
     int wb_rows = 0;                            // optional (GEMM_LINEAR): batched weights -- rows [i * wb_rows, (i + 1) * wb_rows) multiply the
     unsigned wb_stride = 0;                     //   [N][K] matrix at W + i * wb_stride bytes (the VAE's per-image q k^T and P v); M % wb_rows == 0
     float* gn_part = nullptr;                   // optional (16-bit 3x3 convs on 256 x 128 / 256 x 256 tiles): GroupNorm statistics of the OUTPUT from
@@ -190,7 +192,7 @@ inline bool gemm_gn_stats_tile(const GemmArgs& a, int dtype) {
     if (dtype == DSIM_F32 || a.mode != GEMM_CONV3 || a.epi == EPI_GEGLU || a.bias2 || a.Wout <= 0) return false;
     const int hw = a.Hout * a.Wout;
     if ((a.Wout & (a.Wout - 1)) || (hw & (hw - 1)) || hw % 256) return false;
-    if (gemm_skinny_applies(a)) return false;
+    if (!a.force_big && gemm_skinny_applies(a)) return false;
     int bm, bn;
     gemm_launch_tile(a, dtype, &bm, &bn);
     return ((bm == 256 && (bn == 128 || bn == 256)) || (bm == 512 && bn == 128)) && a.N % bn == 0 && hw % bm == 0;

@@ -93,6 +93,7 @@ void gemm_tile_choice(const GemmArgs& a, int* bm, int* bn) {
         const long tiles = (long)((a.M + 255) / 256) * (a.N / bnb);
         want256 = tiles >= 256;
     }
+    if (a.force_big) want256 = (n320 || n256 || n192);
     if (g_force_bm == 128) want256 = 0;                       // development override (kbench A/B)
     if (g_force_bm == 256) want256 = (n320 || n256 || n192);
     if (want256) { *bm = 256; *bn = n320 ? 320 : (n256 ? 256 : 192); return; }
@@ -1024,7 +1025,7 @@ int launch_typed(const GemmArgs& a_in, hipStream_t s) {
     if (a.wb_rows == a.M) a.wb_rows = 0;        // one batch: a plain GEMM
     if constexpr (sizeof(T) == 2) {
         // problems too small to fill the chip: 64 x 64 tiles behind a deep LDS ring, the same arithmetic bit for bit (gemm_skinny.hip)
-        if (g_gemm_skinny && !a.gn_part && !a.wb_rows && gemm_skinny_applies(a)) {
+        if (g_gemm_skinny && !a.gn_part && !a.wb_rows && !a.force_big && gemm_skinny_applies(a)) {
             GemmArgs g = a;
             const int se = gemm_fill_extents(g, sizeof(T));
             return se != DSIM_OK ? se : launch_gemm_skinny(g, s);

@@ -102,7 +102,7 @@ struct WeightStore {
 static inline std::string gemm_family(const GemmArgs& g, int dt, double* flops, double* bytes) {
     int bm, bn;
     gemm_launch_tile(g, dt, &bm, &bn);
-    const bool skinny = dt != DSIM_F32 && !(g.wb_rows && g.wb_rows != g.M) && gemm_skinny_applies(g);      // the small-batch kernel (gemm_skinny.hip)
+    const bool skinny = dt != DSIM_F32 && !(g.wb_rows && g.wb_rows != g.M) && !g.force_big && !g.gn_part && gemm_skinny_applies(g);      // the small-batch kernel (gemm_skinny.hip)
     // 256-row 16-bit conv tiles on power-of-two output maps run the CONV3P instantiation (gemm.hip launch_typed)
     const int hwo = g.Hout * g.Wout;
     const bool conv_p2 = g.mode == GEMM_CONV3 && !skinny && dt != DSIM_F32 && (bm == 256 || bm == 512) && g.Wout > 0 &&

@@ -95,6 +95,10 @@ struct VWalk {
         g.epi = residual ? EPI_RESIDUAL : EPI_NONE; g.residual = residual; g.out = out; g.ldo = N;
         return gemm(g);
     }
+    // The 128 x 128 level (one image = 64 ... 128 of the 256-row tiles): its convs ask for those tiles at EVERY batch size
+    // (GemmArgs.force_big), so that the statistics can come from the epilogue there as well -- a single image then runs that level's
+    // convs on half the chip (+0.1 ms of a ~12 ms encode), every pair or chunk as before
+    static int big_tiles(int hw, int Cout) { return hw >= 128 * 128 && hw % 256 == 0 && Cout % 256 == 0; }
     // GroupNorm statistics of a conv's output from its epilogue (GemmArgs.gn_part) where ONE image alone fills the chip's 256-row
     // tiles (the 512 x 512 and 256 x 256 levels: the same tiles at every batch size, so the numbers do not depend on the batch);
     // `stats` receives the partial buffer for the GroupNorm that consumes the output (null: that GroupNorm runs its own pass)
@@ -109,12 +113,15 @@ struct VWalk {
         if (stats) {
             *stats = nullptr;
             const int hw = g.Hout * g.Wout, cpg = Cout / h->cfg.norm_num_groups;
+            g.force_big = big_tiles(hw, Cout);
             GemmArgs one = g;
             one.M = hw;                                          // the geometry of a single image
             if (h->cfg.norm_num_groups == 32 && Cout % 32 == 0 && (cpg == 4 || cpg == 8 || cpg == 16) && gemm_gn_stats_tile(one, h->dt)) {
                 *stats = (float*)ar->alloc((size_t)batch * (hw / 64) * (Cout / 4) * 2 * sizeof(float));
                 g.gn_part = *stats;
                 g.gn_hw = hw;
+            } else {
+                g.force_big = 0;
             }
         }
         return gemm(g);
@@ -152,6 +159,7 @@ struct VWalk {
             GemmArgs one;
             one.mode = GEMM_CONV3; one.Hout = x.H; one.Wout = x.W; one.Hin = x.H; one.Win = x.W; one.C0 = Cout; one.M = x.H * x.W; one.N = Cout;
             one.K = 9 * Cout; one.epi = EPI_RESIDUAL;
+            one.force_big = big_tiles(x.H * x.W, Cout);
             const int cpg = Cout / h->cfg.norm_num_groups;
             if (out_stats && h->cfg.norm_num_groups == 32 && Cout % 32 == 0 && (cpg == 4 || cpg == 8 || cpg == 16) && gemm_gn_stats_tile(one, h->dt))
                 ostat = (float*)ar->alloc((size_t)n * (x.H * x.W / 64) * (Cout / 4) * 2 * sizeof(float));
@@ -178,7 +186,7 @@ struct VWalk {
             g.A0 = t3.p; g.C0 = t3.C; g.mode = GEMM_CONV3; g.Hin = g.Hout = x.H; g.Win = g.Wout = x.W; g.stride = 1; g.ups = 0; g.pad = 1;
             g.M = M; g.N = Cout; g.K = 9 * t3.C; g.W = c2w->p; g.bias = (const float*)c2b->p;
             g.epi = EPI_RESIDUAL; g.residual = res; g.out = out->p; g.ldo = Cout;
-            if (ostat) { g.gn_part = ostat; g.gn_hw = x.H * x.W; }
+            if (ostat) { g.gn_part = ostat; g.gn_hw = x.H * x.W; g.force_big = big_tiles(x.H * x.W, Cout); }
             CK(gemm(g));
         }
         if (out_stats) *out_stats = ostat;

@@ -14,10 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libdiffsim_amd.so")
-SOURCES = ["gemm.hip", "gemm_skinny.hip", "rowres.hip", "norm.hip", "attention.hip", "attention_fp8.hip", "pack.hip", "unet.hip", "vae.hip", "dit.hip"]
+SOURCES = ["gemm.hip", "gemm_skinny.hip", "rowres.hip", "norm.hip", "attention.hip", "attn160.hip", "attention_fp8.hip", "pack.hip", "unet.hip", "vae.hip", "dit.hip"]
 # the kernel sources written against the 16-bit type h16 are compiled a second time with h16 = fp16 (csrc/common.h): the
 # compute dtype DSIM_F16, which the plain entry points forward to the *_f16 twins
-F16_SOURCES = ["gemm.hip", "gemm_skinny.hip", "rowres.hip", "norm.hip", "attention.hip"]
+F16_SOURCES = ["gemm.hip", "gemm_skinny.hip", "rowres.hip", "norm.hip", "attention.hip", "attn160.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "store.h"), os.path.join(HERE, "..", "include", "diffsim_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -1380,6 +1380,7 @@ int g_attn_q2 = 1;
 int g_attn_dbg = 0;
 int g_attn_short = 1;
 int g_attn_fast_min = 1024;
+int g_tail160 = 1;
 #endif
 
 // Which kernel launch_attention picks for this problem, as the suffix of the profile family name (bench.py maps family names to
@@ -1411,8 +1412,12 @@ int launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
 }
 
 size_t pair_score_scratch_bytes(int n_pairs, int B, int H, int N, int D) {
-    (void)D;
-    return (size_t)n_pairs * 2 * B * H * ((N + 127) / 128) * 4 * sizeof(float);
+    const size_t tiled = (size_t)n_pairs * 2 * B * H * ((N + 127) / 128) * 4 * sizeof(float);
+    if (pair_score160_applies(N, D, DSIM_H16)) {          // (dtype-blind: the 16-bit modes' persistent kernel needs the larger workspace)
+        const size_t pers = pair_score160_scratch_bytes(n_pairs, B, H);
+        return pers > tiled ? pers : tiled;
+    }
+    return tiled;
 }
 
 int launch_pair_score(const void* q, const void* k, const void* v, const int32_t* ia, const int32_t* ib,
@@ -1421,7 +1426,11 @@ int launch_pair_score(const void* q, const void* k, const void* v, const int32_t
     if (n_pairs <= 0 || D % 8 || N < 1) return DSIM_ERR_INVALID;
     if (scratch_bytes < pair_score_scratch_bytes(n_pairs, B, H, N, D)) return DSIM_ERR_WORKSPACE;
     if (n_pairs * 2 > 65535) return DSIM_ERR_INVALID;
-    if (dtype == DSIM_H16) return launch_tail_t<h16>(q, k, v, ia, ib, n_pairs, B, H, N, D, similarity, out, scratch, s, status);
+    if (dtype == DSIM_H16) {
+        if (g_tail160 && pair_score160_applies(N, D, DSIM_H16))
+            return launch_pair_score160(q, k, v, ia, ib, n_pairs, B, H, similarity, out, scratch, scratch_bytes, s, status);
+        return launch_tail_t<h16>(q, k, v, ia, ib, n_pairs, B, H, N, D, similarity, out, scratch, s, status);
+    }
 #ifndef DSIM_H16_IS_F16
     if (dtype == DSIM_F32) return launch_tail_t<float>(q, k, v, ia, ib, n_pairs, B, H, N, D, similarity, out, scratch, s, status);
 #ifdef DSIM_HAS_F16_TWINS

@@ -3,6 +3,7 @@
 // events, random h16 data.  Build: python tools/build_kbench.py ; run on the GPU box:
 //   ./tools/kbench [B2=64] [iters=10] [filter]
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -298,6 +299,193 @@ static void bench_attn(const char* name, int B, int Bkv, int H, int Nq, int Nk, 
     HC(hipFree(q)); if (kv) HC(hipFree(kv)); HC(hipFree(out));
 }
 
+
+
+// host reference of one pair's score (double precision; the SDPA outputs rounded to bf16 as the 16-bit kernels do)
+static float bf16_round(float x) { unsigned u; memcpy(&u, &x, 4); u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u; float r; memcpy(&r, &u, 4); return r; }
+static double tail_reference(const std::vector<unsigned short>& q, const std::vector<unsigned short>& k, const std::vector<unsigned short>& v,
+                             int ia, int ib, int B, int H, int N, int D, int mse) {
+    auto f = [](unsigned short h) { unsigned u = (unsigned)h << 16; float r; memcpy(&r, &u, 4); return (double)r; };
+    const int C = H * D;
+    const size_t img = (size_t)B * N * C;
+    double res = 0;
+    std::vector<double> os((size_t)N * D), ox((size_t)N * D), p(N);
+    for (int dir = 0; dir < 2; ++dir) {
+        const int iq = dir ? ib : ia, ix = dir ? ia : ib;
+        double sxy = 0, sxx = 0, syy = 0, sd = 0;
+        for (int b = 0; b < B; ++b)
+            for (int h = 0; h < H; ++h) {
+                const size_t off = (size_t)b * N * C + h * D;
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int ik = pass ? ix : iq;
+                    std::vector<double>& o = pass ? ox : os;
+                    for (int i = 0; i < N; ++i) {
+                        double mx = -1e300;
+                        for (int j = 0; j < N; ++j) {
+                            double a = 0;
+                            for (int d = 0; d < D; ++d) a += f(q[iq * img + off + (size_t)i * C + d]) * f(k[ik * img + off + (size_t)j * C + d]);
+                            p[j] = a / sqrt((double)D);
+                            mx = std::max(mx, p[j]);
+                        }
+                        double l = 0;
+                        for (int j = 0; j < N; ++j) { p[j] = exp(p[j] - mx); l += p[j]; }
+                        for (int d = 0; d < D; ++d) {
+                            double a = 0;
+                            for (int j = 0; j < N; ++j) a += p[j] * f(v[ik * img + off + (size_t)j * C + d]);
+                            o[(size_t)i * D + d] = (double)bf16_round((float)(a / l));
+                        }
+                    }
+                }
+                for (size_t e = 0; e < (size_t)N * D; ++e) {
+                    sxy += ox[e] * os[e]; sxx += ox[e] * ox[e]; syy += os[e] * os[e]; sd += (ox[e] - os[e]) * (ox[e] - os[e]);
+                }
+            }
+        res += mse ? sd / ((double)B * H * N * D) : sxy / (std::max(sqrt(sxx), 1e-8) * std::max(sqrt(syy), 1e-8));
+    }
+    return res * 0.5;
+}
+
+// the fused score tail at SD1.5's default tap (256 tokens x 8 heads x 160): pair_tail_kernel against pair_tail160_kernel (attn160.hip)
+static void bench_tail(const char* name, int np, int iters, Timer& t) {
+    if (!want(name)) return;
+    const int B = 2, H = 8, N = 256, D = 160, C = H * D;
+    const size_t per = (size_t)2 * np * B * N * C;
+    void* q = dalloc_bf16(per, 11, 2.0f);
+    void* k = dalloc_bf16(per, 12, 2.0f);
+    void* v = dalloc_bf16(per, 13, 1.0f);
+    std::vector<int32_t> ha(np), hb(np);
+    for (int i = 0; i < np; ++i) { ha[i] = 2 * i; hb[i] = 2 * i + 1; }
+    int32_t *ia, *ib;
+    HC(hipMalloc((void**)&ia, np * 4)); HC(hipMalloc((void**)&ib, np * 4));
+    HC(hipMemcpy(ia, ha.data(), np * 4, hipMemcpyHostToDevice)); HC(hipMemcpy(ib, hb.data(), np * 4, hipMemcpyHostToDevice));
+    const size_t sb = pair_score_scratch_bytes(np, B, H, N, D);
+    void* scratch; HC(hipMalloc(&scratch, sb));
+    float *o0, *o1;
+    HC(hipMalloc((void**)&o0, np * 4)); HC(hipMalloc((void**)&o1, np * 4));
+    int st0 = 0, st1 = 0;
+    const int rounds = getenv("KB_ROUNDS") ? atoi(getenv("KB_ROUNDS")) : 5;
+    for (int sim = 0; sim < 2; ++sim) {
+        std::vector<float> m0, m1;
+        for (int r = 0; r < rounds; ++r) {
+            g_tail160 = 0;
+            m0.push_back(t.run([&] { st0 = launch_pair_score(q, k, v, ia, ib, np, B, H, N, D, DSIM_BF16, sim, o0, scratch, sb, 0); }, iters));
+            g_tail160 = 1;
+            m1.push_back(t.run([&] { st1 = launch_pair_score(q, k, v, ia, ib, np, B, H, N, D, DSIM_BF16, sim, o1, scratch, sb, 0); }, iters));
+        }
+        HC(hipDeviceSynchronize());
+        std::vector<float> h0(np), h1(np);
+        HC(hipMemcpy(h0.data(), o0, np * 4, hipMemcpyDeviceToHost)); HC(hipMemcpy(h1.data(), o1, np * 4, hipMemcpyDeviceToHost));
+        double md = 0;
+        for (int i = 0; i < np; ++i) md = std::max(md, (double)fabsf(h0[i] - h1[i]) / std::max(1e-12, (double)fabsf(h0[i])));
+        std::sort(m0.begin(), m0.end()); std::sort(m1.begin(), m1.end());
+        const double fl = 2.0 * np * B * H * 2 * 4.0 * N * N * D;
+        printf("%-20s %s pairs=%3d  tiled %8.4f/%8.4f ms %7.1f TF/s | persistent d160 %8.4f/%8.4f ms %7.1f TF/s (min/median)  max rel diff %.3g  score[0] %.6f / %.6f st=%d/%d\n",
+               name, sim ? "mse   " : "cosine", np, m0[0], m0[rounds / 2], fl / m0[rounds / 2] / 1e9, m1[0], m1[rounds / 2], fl / m1[rounds / 2] / 1e9, md,
+               h0[0], h1[0], st0, st1);
+        if (getenv("KB_TAILDBG") && sim == 0) {
+            // the first unit (pair 0, direction 0, b 0, head 0): both attention outputs against a host evaluation, error by key-independent position
+            float* dbg; HC(hipMalloc((void**)&dbg, 2 * N * D * 4)); HC(hipMemset(dbg, 0, 2 * N * D * 4));
+            g_tail160_dbg = dbg; g_tail160 = 1;
+            launch_pair_score(q, k, v, ia, ib, np, B, H, N, D, DSIM_BF16, sim, o1, scratch, sb, 0);
+            HC(hipDeviceSynchronize());
+            g_tail160_dbg = nullptr;
+            std::vector<float> hd(2 * N * D);
+            HC(hipMemcpy(hd.data(), dbg, hd.size() * 4, hipMemcpyDeviceToHost));
+            std::vector<unsigned short> hq(per), hk(per), hv(per);
+            HC(hipMemcpy(hq.data(), q, per * 2, hipMemcpyDeviceToHost)); HC(hipMemcpy(hk.data(), k, per * 2, hipMemcpyDeviceToHost));
+            HC(hipMemcpy(hv.data(), v, per * 2, hipMemcpyDeviceToHost));
+            auto f = [](unsigned short h) { unsigned u = (unsigned)h << 16; float r; memcpy(&r, &u, 4); return (double)r; };
+            const size_t img = (size_t)B * N * C;
+            std::vector<double> p2v(N);
+            for (int pass = 0; pass < 2; ++pass) {
+                const int iq = ha[0], ik = pass ? hb[0] : ha[0];
+                double worst = 0; int wi = -1, wd = -1;
+                std::vector<double> errq(N, 0.0), errd(D, 0.0), p(N);
+                for (int i = 0; i < N; ++i) {
+                    double mx = -1e300;
+                    for (int j = 0; j < N; ++j) {
+                        double a = 0;
+                        for (int d = 0; d < D; ++d) a += f(hq[iq * img + (size_t)i * C + d]) * f(hk[ik * img + (size_t)j * C + d]);
+                        p[j] = a / sqrt((double)D); mx = std::max(mx, p[j]);
+                    }
+                    double l = 0;
+                    for (int j = 0; j < N; ++j) { p[j] = exp(p[j] - mx); l += p[j]; }
+                    for (int d = 0; d < D; ++d) {
+                        double a = 0;
+                        for (int j = 0; j < N; ++j) a += p[j] * f(hv[ik * img + (size_t)j * C + d]);
+                        const double e = fabs(a / l - hd[((size_t)pass * N + i) * D + d]);
+                        errq[i] = std::max(errq[i], e); errd[d] = std::max(errd[d], e);
+                        if (e > worst) { worst = e; wi = i; wd = d; }
+                    }
+                }
+                printf("   dbg pass %d: worst |err| %.4g at query %d d %d\n     per query:", pass, worst, wi, wd);
+                for (int i = 0; i < N; ++i) printf(" %.2g", errq[i]);
+                printf("\n     per d:");
+                for (int d = 0; d < D; ++d) printf(" %.2g", errd[d]);
+                printf("\n");
+            }
+            {
+                printf("   sums of the dumped f32 outputs, unit 0 per wave [x.y x.x y.y] (f32 values and rounded to bf16):\n    ");
+                for (int w = 0; w < 8; ++w) {
+                    double a = 0, b2 = 0, c2 = 0, ar = 0, br = 0, cr = 0;
+                    for (int e = w * 32 * D; e < (w + 1) * 32 * D; ++e) {
+                        const double y = hd[e], x = hd[(size_t)N * D + e], yr = bf16_round(hd[e]), xr = bf16_round(hd[(size_t)N * D + e]);
+                        a += x * y; b2 += x * x; c2 += y * y; ar += xr * yr; br += xr * xr; cr += yr * yr;
+                    }
+                    printf(" [%.4f %.3f %.3f | %.4f %.3f %.3f]", a, b2, c2, ar, br, cr);
+                }
+                printf("\n");
+            }
+            HC(hipFree(dbg));
+            // per-unit partial sums of pair 0 against the host (x.y, x.x, y.y)
+            std::vector<float> hp((size_t)2 * B * H * 8 * 4);
+            HC(hipMemcpy(hp.data(), scratch, hp.size() * 4, hipMemcpyDeviceToHost));
+            std::vector<double> os((size_t)N * D), ox((size_t)N * D);
+            for (int dir = 0; dir < 2; ++dir)
+                for (int b = 0; b < B; ++b)
+                    for (int h = 0; h < H; ++h) {
+                        const int iq = dir ? hb[0] : ha[0], ix = dir ? ha[0] : hb[0];
+                        const size_t off = (size_t)b * N * C + h * D;
+                        for (int pass = 0; pass < 2; ++pass) {
+                            const int ik = pass ? ix : iq;
+                            std::vector<double>& o = pass ? ox : os;
+                            for (int i = 0; i < N; ++i) {
+                                double mx = -1e300;
+                                for (int j = 0; j < N; ++j) {
+                                    double a = 0;
+                                    for (int d = 0; d < D; ++d) a += f(hq[iq * img + off + (size_t)i * C + d]) * f(hk[ik * img + off + (size_t)j * C + d]);
+                                    p2v[j] = a / sqrt((double)D); mx = std::max(mx, p2v[j]);
+                                }
+                                double l = 0;
+                                for (int j = 0; j < N; ++j) { p2v[j] = exp(p2v[j] - mx); l += p2v[j]; }
+                                for (int d = 0; d < D; ++d) {
+                                    double a = 0;
+                                    for (int j = 0; j < N; ++j) a += p2v[j] * f(hv[ik * img + off + (size_t)j * C + d]);
+                                    o[(size_t)i * D + d] = (double)bf16_round((float)(a / l));
+                                }
+                            }
+                        }
+                        printf("   unit dir %d b %d h %d:", dir, b, h);
+                        for (int w = 0; w < 8; ++w) {
+                            double sxy = 0, sxx = 0, syy = 0;
+                            for (size_t e = (size_t)w * 32 * D; e < (size_t)(w + 1) * 32 * D; ++e) { sxy += ox[e] * os[e]; sxx += ox[e] * ox[e]; syy += os[e] * os[e]; }
+                            const float* g = &hp[(((size_t)dir * B * H + b * H + h) * 8 + w) * 4];
+                            printf(" [%.4f/%.4f %.3f/%.3f %.3f/%.3f]", g[0], sxy, g[1], sxx, g[2], syy);
+                        }
+                        printf("\n");
+                    }
+        }
+        if (getenv("KB_TAILREF")) {
+            std::vector<unsigned short> hq(per), hk(per), hv(per);
+            HC(hipMemcpy(hq.data(), q, per * 2, hipMemcpyDeviceToHost)); HC(hipMemcpy(hk.data(), k, per * 2, hipMemcpyDeviceToHost));
+            HC(hipMemcpy(hv.data(), v, per * 2, hipMemcpyDeviceToHost));
+            const int pi = np - 1;
+            printf("   host reference pair %d: %.7f   tiled %.7f   persistent %.7f\n", pi, tail_reference(hq, hk, hv, ha[pi], hb[pi], B, H, N, D, sim), h0[pi], h1[pi]);
+        }
+    }
+    HC(hipFree(q)); HC(hipFree(k)); HC(hipFree(v)); HC(hipFree(ia)); HC(hipFree(ib)); HC(hipFree(scratch)); HC(hipFree(o0)); HC(hipFree(o1));
+}
+
 static void bench_gn(const char* name, int B, int HW, int C, int iters, Timer& t) {
     if (!want(name)) return;
     void* x = dalloc_bf16((size_t)B * HW * C, 1);
@@ -536,6 +724,8 @@ int main(int argc, char** argv) {
     bench_attn("attn_cross_4096_d40", B2, 2, 8, 4096, 77, 40, iters, t);
     bench_attn("attn_cross_1024_d80", B2, 2, 8, 1024, 77, 80, iters, t);
     bench_attn("attn_cross_256_d160", B2, 2, 8, 256, 77, 160, iters, t);
+    bench_tail("tail_256_d160", std::max(1, B2 / 4), iters, t);
+    bench_tail("tail_256_d160_1pair", 1, iters, t);
     bench_attn("attn_dit_256_d72", B2, B2, 16, 256, 256, 72, iters, t);
     bench_attn("attn_sdxl_self_4096_d64", B2, B2, 10, 4096, 4096, 64, iters, t);
     bench_attn("attn_sdxl_self_1024_d64", B2, B2, 20, 1024, 1024, 64, iters, t);

@@ -14,7 +14,7 @@
 //     32 w .. 32 w + 31 of the unit's 256, so the 256 keys of an attention are staged ONCE for all of its queries.
 //   - EVERYTHING arrives by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KB per wave instruction) issued from inline asm, so that
 //     the compiler's own s_waitcnt bookkeeping never sees a vector-memory load in the loop and never drains the stream:
-//     K and V as 32-key tiles (10 KB + 10 KB) through a 4-slot ring, THREE tiles ahead, one s_barrier per tile behind a
+//     K and V as 32-key tiles (10 KB + 10 KB) through a 4-slot ring, three to four tiles ahead, one s_barrier per tile behind a
 //     COUNTED vmcnt; the NEXT unit's Q rows into a wave-private 10 KB slab, one piece per tile step.  The stream does not
 //     stop at unit borders: the last three steps of a unit issue the first three tiles of the next.
 //   - dense 320-byte rows in LDS, no padding: K and Q chunks are XOR-swizzled in their low two bits by (row >> 2) & 3 (applied by
@@ -39,7 +39,7 @@ constexpr int A_ROWB = A_D * 2;                 // bytes per (row, head) in the 
 constexpr int A_KTILE = A_KT * A_ROWB;          // 10240: one K (or V) tile image, also one wave's Q slab
 constexpr int A_SLOT = 2 * A_KTILE;             // K tile + V tile
 constexpr int A_NSLOT = 4;
-constexpr int A_LOOK = A_NSLOT - 1;             // tiles in flight ahead of the one being read
+constexpr int A_PRE = 3;                        // fragment reads in flight ahead of the MFMA that consumes them
 constexpr int A_RING = A_NSLOT * A_SLOT;        // 81920
 constexpr int A_LDS = A_RING + 8 * A_KTILE;     // 163840 bytes: all of a CU's LDS, one workgroup per CU
 constexpr int A_NKS = A_D / 16;                 // 10 k steps over d (QK^T)
@@ -57,7 +57,45 @@ __device__ __forceinline__ float max_halves160(float x) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// v_max3_f32 as ONE instruction: fmaxf on MFMA outputs draws a canonicalising v_max(x, x) per operand from hipcc
+__device__ __forceinline__ float max3(float a, float b, float c3) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c3));
+    return r;
+}
+constexpr float A_THR = 8.0f;                   // log2 units a row maximum may grow past the softmax reference before a rescale
+
+// x + (the value in the lane 32 away): one v_permlane32_swap instead of a ds_bpermute round trip
+__device__ __forceinline__ float half_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sum over the 64 lanes (wave-uniform result): DPP row shifts leave every 16-lane row's sum in its last lane, four readlanes add
+// the rows -- VALU only (the __shfl_xor tree is six dependent LDS round trips per value), in a fixed order
+__device__ __forceinline__ float wave_sum(float x) {
+    int v = __float_as_int(x);
+#define DSIM_DPP_ADD(ctrl) v = __float_as_int(__int_as_float(v) + __int_as_float(__builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, false)))
+    DSIM_DPP_ADD(0x111);            // row_shr:1
+    DSIM_DPP_ADD(0x112);            // row_shr:2
+    DSIM_DPP_ADD(0x114);            // row_shr:4
+    DSIM_DPP_ADD(0x118);            // row_shr:8   -> lane 15 of every row holds the row's sum
+#undef DSIM_DPP_ADD
+    return (__int_as_float(__builtin_amdgcn_readlane(v, 15)) + __int_as_float(__builtin_amdgcn_readlane(v, 31))) +
+           (__int_as_float(__builtin_amdgcn_readlane(v, 47)) + __int_as_float(__builtin_amdgcn_readlane(v, 63)));
+}
+
 template <int N> struct IC { static constexpr int value = N; };
+
+// In-kernel phase stamps (-DDSIM_DEVTOOLS -DDSIM_STAMPS builds of tools/kbench only; the s_waitcnt behind each s_memtime also
+// drains the wave's LDS reads, so a stamped build is slower and less pipelined than the product -- it says where time goes, not how much)
+#if defined(DSIM_DEVTOOLS) && defined(DSIM_STAMPS)
+#define TSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tst_[i]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define TSTAMP_ACC(i) tsa_[i] += tst_[(i) + 1] - tst_[i]
+#else
+#define TSTAMP(i) do { } while (0)
+#define TSTAMP_ACC(i) do { } while (0)
+#endif
 
 // s_waitcnt vmcnt(N) for a compile-time N (the ring's counted waits)
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
@@ -77,19 +115,21 @@ __device__ __forceinline__ u32x4 make_desc(const void* p, unsigned bytes) {
     return d;
 }
 
+// a unit's tensors as BYTE offsets into the three allocations (q, k and v have one layout, so two offsets describe all five views:
+// four scalar registers per unit instead of ten; the descriptors are formed from them at the point of issue)
 struct Unit160 {
-    const h16* q;
-    const h16* ks; const h16* vs;       // the query image's own keys / values ("self")
-    const h16* kx; const h16* vx;       // the other image's ("cross")
+    unsigned long long oq;              // the query image's rows (Q, and its own K / V: "self")
+    unsigned long long ox;              // the other image's K / V ("cross")
     int pidx;                           // this wave's slot in the partial array
 };
 
 __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restrict__ qg, const h16* __restrict__ kg,
                                                               const h16* __restrict__ vg, const int32_t* __restrict__ idx_a,
                                                               const int32_t* __restrict__ idx_b, const int n_pairs, const int B,
-                                                              const int H, const float c, const int mse, float* __restrict__ part
+                                                              const int H, const float c, const int mse,
+                                                              float* __restrict__ part, char* __restrict__ park
 #ifdef DSIM_DEVTOOLS
-                                                              , float* __restrict__ dbg
+                                                              , float* __restrict__ dbg, const int exp
 #endif
                                                               ) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -106,15 +146,15 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
 
     // ---- DMA pieces.  A piece is 1 KB = 3.2 dense rows of a 32-row image: lane i writes LDS byte 1024 p + 16 i and chooses its
     // source chunk (K, Q: swizzled).  The lane pattern repeats every 5 pieces = 16 rows.
-    auto piece_voff = [&](int pat, bool swizzle) {
-        const int f = 64 * pat + lane;
+    auto piece_voff = [&](int pat, bool swizzle, int ln, int rb) {
+        const int f = 64 * pat + ln;
         const int r = (f * 3277) >> 16, pos = f - r * 20;            // f / 20, f % 20 (f < 320)
         const int ch = swizzle ? ((pos & ~3) | ((pos & 3) ^ (r >> 2))) : pos;
-        return r * rowb + ch * 16;
+        return r * rb + ch * 16;
     };
     // K / V: this wave's pieces of a tile are j = wave, wave + 8, wave + 16 (< 20) of [K pieces 0..9 | V pieces 0..9]: waves 0-3 issue
     // three, waves 4-7 two (the two waves of a SIMD five together)
-    int kv_voff[3], kv_soff[3];
+    int kv_voff[3], kv_grp[3];
     unsigned kv_lds[3];
     bool kv_isv[3];
 #pragma unroll
@@ -123,24 +163,50 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
         kv_isv[j] = pj >= 10;
         const int p = kv_isv[j] ? pj - 10 : pj;
         const int grp = p >= 5, pat = p - 5 * grp;
-        kv_voff[j] = piece_voff(pat, !kv_isv[j]);
-        kv_soff[j] = grp * 16 * rowb;
+        kv_voff[j] = piece_voff(pat, !kv_isv[j], lane, rowb);
+        kv_grp[j] = grp;
         kv_lds[j] = (kv_isv[j] ? A_KTILE : 0) + p * 1024;
     }
+#ifdef DSIM_DEVTOOLS
+#define T160_ABL(bit) (exp & (bit))
+#else
+#define T160_ABL(bit) false
+#endif
     const bool three = wave < 4;
-    auto issue_kv = [&](const h16* kp, const h16* vp, int tile, int slot) {
-        const u32x4 dK = make_desc(kp, recs), dV = make_desc(vp, recs);
-        const unsigned sb = lbase + slot * A_SLOT;
-        const int ts = tile * A_KT * rowb;
-        dma_piece(sb + kv_lds[0], kv_voff[0], dK, ts + kv_soff[0]);                                 // j = 0: always a K piece
-        dma_piece(sb + kv_lds[1], kv_voff[1], kv_isv[1] ? dV : dK, ts + kv_soff[1]);
-        if (three) dma_piece(sb + kv_lds[2], kv_voff[2], dV, ts + kv_soff[2]);                      // j = 2: always a V piece
+#ifdef DSIM_DEVTOOLS
+    if (exp & 512) { kv_voff[0] = lane * 16; kv_voff[1] = lane * 16 + 1024; kv_voff[2] = lane * 16 + 2048; }
+    {   // kbench: static wave priority (exp bits 0-1: level; bit 2: for waves 4-7 instead of 0-3)
+        const bool mine = (exp & 4) ? !three : three;
+        if (mine) {
+            if ((exp & 3) == 1) __builtin_amdgcn_s_setprio(1);
+            else if ((exp & 3) == 2) __builtin_amdgcn_s_setprio(2);
+            else if ((exp & 3) == 3) __builtin_amdgcn_s_setprio(3);
+        }
+    }
+#endif
+    auto issue_kv = [&](unsigned long long uoff, int tile, int slot) {
+        if (T160_ABL(16)) return;            // kbench ablation: no DMA after the prologue's (timing only)
+        const u32x4 dK = make_desc((const char*)kg + uoff, recs), dV = make_desc((const char*)vg + uoff, recs);
+        // (scalars re-derived per hand-over from an opaque copy: hipcc otherwise hoists ~60 loop-invariant offsets out of the unit loop,
+        // parks them in VGPR lanes and pays a v_readlane + hazard padding for each in front of the DMA that uses it)
+        int rb = rowb;
+        unsigned lb = lbase;
+        asm volatile("" : "+s"(rb), "+s"(lb));
+        const unsigned sb = lb + slot * A_SLOT;
+        const int ts = tile * A_KT * rb;
+        dma_piece(sb + kv_lds[0], kv_voff[0], dK, ts + kv_grp[0] * 16 * rb);                        // j = 0: always a K piece
+        dma_piece(sb + kv_lds[1], kv_voff[1], kv_isv[1] ? dV : dK, ts + kv_grp[1] * 16 * rb);
+        if (three) dma_piece(sb + kv_lds[2], kv_voff[2], dV, ts + kv_grp[2] * 16 * rb);             // j = 2: always a V piece
     };
     // Q: piece j (0..9) of this wave's 32 rows into its slab
     const unsigned qslab = lbase + A_RING + wave * A_KTILE;
-    auto issue_q = [&](const h16* qp, int j) {
-        const u32x4 dQ = make_desc(qp, recs);
-        dma_piece(qslab + j * 1024, piece_voff(j % 5, true), dQ, (wave * 32 + 16 * (j / 5)) * rowb);
+    auto issue_q = [&](unsigned long long uoff, int j) {
+        if (T160_ABL(16)) return;
+        const u32x4 dQ = make_desc((const char*)qg + uoff, recs);
+        int ln = lane, rb = rowb;
+        unsigned qs = qslab;
+        asm volatile("" : "+v"(ln), "+s"(rb), "+s"(qs));     // recomputed per piece (see issue_kv; five hoisted lane patterns would be spilled too)
+        dma_piece(qs + j * 1024, piece_voff(j % 5, true, ln, rb), dQ, (wave * 32 + 16 * (j / 5)) * rb);
     };
 
     // ---- fragment read addresses (bytes inside a 32-row image / a slot) ------------------------------------------------------
@@ -154,10 +220,9 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
         const int pair = p2 / BH, bh = p2 - pair * BH, b = bh / H, h = bh - b * H;
         const int ia = __builtin_amdgcn_readfirstlane(idx_a[pair]), ib = __builtin_amdgcn_readfirstlane(idx_b[pair]);
         const int iq = dir ? ib : ia, ix = dir ? ia : ib;
-        const size_t off = (size_t)b * A_N * ld + h * A_D;
-        u.q = qg + iq * img + off;
-        u.ks = kg + iq * img + off; u.vs = vg + iq * img + off;
-        u.kx = kg + ix * img + off; u.vx = vg + ix * img + off;
+        const unsigned long long off = ((unsigned long long)b * A_N * ld + h * A_D) * 2ull;
+        u.oq = (unsigned long long)iq * (img * 2) + off;
+        u.ox = (unsigned long long)ix * (img * 2) + off;
         u.pidx = ((pair * 2 + dir) * BH + bh) * 8 + wave;
         return u;
     };
@@ -174,19 +239,30 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
     if (p20 >= total) return;
     Unit160 cur = setup(p20);
 #pragma unroll
-    for (int j = 0; j < 10; ++j) issue_q(cur.q, j);
+    for (int j = 0; j < 10; ++j) issue_q(cur.oq, j);
 #pragma unroll
-    for (int t = 0; t < A_LOOK; ++t) issue_kv(cur.ks, cur.vs, t, t);
-    if (three) wait_vm<3 * A_LOOK>(); else wait_vm<2 * A_LOOK>();
+    for (int t = 0; t < A_NSLOT - 1; ++t) issue_kv(cur.oq, t, t);
+    if (three) issue_kv(cur.oq, A_NSLOT - 1, A_NSLOT - 1);        // (waves 4-7 issue it in step 0: see the hand-over)
+    if (three) wait_vm<3 * A_NSLOT>(); else wait_vm<2 * (A_NSLOT - 1)>();
     read_q();
+    // tile 0 visible to every wave; its first K fragments
+    if (three) wait_vm<3 * (A_NSLOT - 1)>(); else wait_vm<2 * (A_NSLOT - 2)>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    h16x8 kpre[A_PRE];
+#pragma unroll
+    for (int ks = 0; ks < A_PRE; ++ks) kpre[ks] = *reinterpret_cast<const h16x8*>(smem + ((ks & 1) ? e1 : e0) + (ks >> 1) * 64);
 
     f32x16 o[A_NDB];
     float m_run = 0.f, l_run = 0.f;
-    u32x4 ypk[2 * A_NDB];
+    const float thr = A_THR / c;                    // the threshold in raw-logit units
+    // the self pass's output waits for the cross pass in a 10 KB slab per wave of the workspace (L2-resident: written and read
+    // back by the same CU a few microseconds apart) instead of 40 registers held through eight steps
+    const u32x4 dP = make_desc(park + ((size_t)blockIdx.x * 8 + wave) * A_KTILE, A_KTILE);
 
     // the pass's output, normalised and rounded to the compute dtype, two values per register (d = 32 db + (r & 3) + 8 (r >> 2) + 4 half)
     auto pack_o = [&](u32x4 (&pk)[2 * A_NDB]) {
-        const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+        const float inv = __builtin_amdgcn_rcpf(half_sum(l_run));      // (v_rcp_f32: 1 ulp, against the 8 bits the outputs keep)
         typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int db = 0; db < A_NDB; ++db)
@@ -197,47 +273,87 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
             }
     };
 
+#if defined(DSIM_DEVTOOLS) && defined(DSIM_STAMPS)
+    unsigned long long tst_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tsa_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (;;) {
         const int p2n = ((it + 1) * npc + cj) * 8 + xcd;
         const bool has_next = p2n < total;
         // (no next unit: the look-ahead re-fetches this unit's own tiles and rows -- same instruction counts, no special cases)
         const Unit160 nxt = has_next ? setup(p2n) : cur;
 
-        // One 32-key tile; steps 0-7 are the self pass, 8-15 the cross pass.  Vector-memory operations per step in issue order:
-        // in steps 0-9 one Q piece of the next unit, then the K / V pieces of the tile three steps ahead (3 or 2 per wave).
-        // Step T reads the tile issued three steps earlier, so its wait leaves everything issued since then in flight.
+        // One 32-key tile; steps 0-7 are the self pass, 8-15 the cross pass.  A step is  QK^T(T) . softmax(T) . PV(T), and the
+        // hand-over to tile T + 1 sits INSIDE the PV: once the step's last V^T fragments are in registers (three MFMAs before its
+        // end) the wave waits for its own DMA pieces of tile T + 1, meets the others at the barrier, issues the DMA of tile T + 4
+        // into the slot tile T just left and the first K fragment reads of tile T + 1 -- and runs the remaining three MFMAs from
+        // registers while those reads are in flight, instead of idling on LDS latency behind every barrier.
+        // Vector-memory operations per hand-over in issue order: in steps 0-9 one Q piece of the next unit, then the K / V pieces of
+        // tile T + 4 (3 or 2 per wave).  The hand-over of step T needs the pieces issued three hand-overs earlier.
         auto step = [&](auto tc) {
             constexpr int T = decltype(tc)::value;
-            constexpr int QP = (T >= 2 && T <= 11 ? 1 : 0) + (T >= 1 && T <= 10 ? 1 : 0);     // Q pieces issued in steps T - 2 and T - 1
-            if (three) wait_vm<6 + QP>(); else wait_vm<4 + QP>();
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            {
-                constexpr int TN = T + A_LOOK;
-                if constexpr (T < 10) issue_q(nxt.q, T);
-                if constexpr (TN < 16) issue_kv(TN < 8 ? cur.ks : cur.kx, TN < 8 ? cur.vs : cur.vx, TN & 7, TN & 3);
-                else issue_kv(nxt.ks, nxt.vs, TN - 16, TN & 3);
-            }
+            const bool idle = (T160_ABL(128) && !three) || (T160_ABL(256) && three);          // kbench ablation 128: waves 4-7 only stage (one computing wave per SIMD)
             constexpr bool FIRST = (T & 7) == 0;
             const char* sb = smem + (T & 3) * A_SLOT;
-            // ---- S^T = K Q^T: keys x this lane's query column, raw (unscaled) logits ----------------------------------------
+            TSTAMP(0);
+            // ---- S^T = K Q^T: keys x this lane's query column, raw (unscaled) logits; fragments A_PRE reads ahead -------------
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            h16x8 kf[A_PRE + 1];
+#pragma unroll
+            for (int i = 0; i < A_PRE; ++i) kf[i] = kpre[i];
+            if (!idle) {
 #pragma unroll
             for (int ks = 0; ks < A_NKS; ++ks) {
-                const h16x8 kf = *reinterpret_cast<const h16x8*>(sb + ((ks & 1) ? e1 : e0) + (ks >> 1) * 64);
-                s = H16_MFMA_32x32x16(kf, q[ks], s, 0, 0, 0);
+                if (ks + A_PRE < A_NKS)
+                    kf[(ks + A_PRE) % (A_PRE + 1)] = *reinterpret_cast<const h16x8*>(sb + (((ks + A_PRE) & 1) ? e1 : e0) + ((ks + A_PRE) >> 1) * 64);
+                __builtin_amdgcn_sched_barrier(0);
+                s = H16_MFMA_32x32x16(kf[ks % (A_PRE + 1)], q[ks], s, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // ---- online softmax -------------------------------------------------------------------------------------------
-            float tmax = fmaxf(s[0], s[1]);
+            }
+            TSTAMP(1);
+            u32x4 ypk[2 * A_NDB];
+            if constexpr (T == 15) {
+                // Q is dead: the parked self output comes back into its registers.  Inline asm, so that hipcc does not wait for these
+                // loads with a count that ignores the DMA pieces behind them; they are OLDER than this step's hand-over pieces, so the
+                // epilogue's counted wait covers them and leaves the pieces in flight.  sc1: served by L2 -- this CU's L1 may still hold
+                // the slab's lines from the previous unit's read-back.  s_nop 4: an SGPR operand hipcc has just restored from a VGPR lane
+                // (v_readlane) needs five wait states before a VMEM reads it, and hipcc pads nothing inside an asm statement.
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const int po = ln * 16;
 #pragma unroll
-            for (int r = 2; r < 16; r += 2) tmax = fmaxf(tmax, fmaxf(s[r], s[r + 1]));
+                for (int i = 0; i < 2 * A_NDB; ++i)
+                    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen sc1" : "=v"(ypk[i]) : "v"(po), "s"(dP), "s"(i * 1024) : "memory");
+            }
+            // the first V^T fragments: their LDS latency passes under the softmax
+            const char* vb = sb + vl;
+            auto vread = [&](int j) {                   // fragment of PV MFMA j = 5 s2 + db
+                const char* pa = vb + (j / A_NDB) * 16 * A_ROWB + (j % A_NDB) * 64;
+                const h16x4 lo = h16_ds_read_tr16_b64(pa);
+                const h16x4 hi = h16_ds_read_tr16_b64(pa + 8 * A_ROWB);
+                h16x8 vf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+                return vf;
+            };
+            h16x8 vf[A_PRE + 1];
+#pragma unroll
+            for (int j = 0; j < A_PRE; ++j) vf[j] = vread(j);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- online softmax -------------------------------------------------------------------------------------------
+            // The reference point m_run moves only when some row's maximum has grown by more than A_THR (log2 units): softmax is
+            // invariant to it, P <= 2^A_THR keeps its relative precision in either 16-bit type, and the sums are f32.  (With the
+            // exact rule the rescale -- 80 multiplies against the step's 20 MFMAs -- ran in nearly every step: one of 32 rows
+            // almost always finds a new maximum among 32 more keys.)
+            float tmax = max3(max3(s[0], s[1], s[2]), max3(s[3], s[4], s[5]), max3(s[6], s[7], s[8]));
+            tmax = max3(tmax, max3(s[9], s[10], s[11]), max3(s[12], s[13], max3(s[14], s[15], s[15])));
             tmax = max_halves160(tmax);
             if constexpr (FIRST) {
                 m_run = tmax;
             } else {
-                if (!__all(tmax <= m_run)) {            // some row's maximum grew: exact rescale (alpha == 1 for the other rows)
+                if (!__all(tmax <= m_run + thr)) {
                     const float mn = fmaxf(m_run, tmax);
                     const float alpha = __builtin_amdgcn_exp2f((m_run - mn) * c);
                     m_run = mn;
@@ -249,41 +365,87 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
                 }
             }
             const float mc = -m_run * c;
-            float psum = 0.f;
+            if (!T160_ABL(8) && !idle) {            // (kbench ablation 8: no exponentials)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c, mc));
-                psum += s[r];
+                for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c, mc));
             }
+            const float psum = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) +
+                               (((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15])));
             l_run = FIRST ? psum : l_run + psum;
             h16x8 pf[2];
 #pragma unroll
             for (int f = 0; f < 2; ++f)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pf[f][e] = (h16)s[8 * f + e];
-            // ---- O^T += V^T P^T -------------------------------------------------------------------------------------------
-            const char* vb = sb + vl;
+            // ---- O^T += V^T P^T, and the hand-over to tile T + 1 ---------------------------------------------------------------
+            constexpr int NPV = 2 * A_NDB;
+            TSTAMP(2);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int db = 0; db < A_NDB; ++db) {
-                    const char* pa = vb + s2 * 16 * A_ROWB + db * 64;
-                    const h16x4 lo = h16_ds_read_tr16_b64(pa);
-                    const h16x4 hi = h16_ds_read_tr16_b64(pa + 8 * A_ROWB);
-                    h16x8 vf;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
-                    if (FIRST && s2 == 0) {
-                        f32x16 z;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                        o[db] = H16_MFMA_32x32x16(vf, pf[s2], z, 0, 0, 0);
-                    } else {
-                        o[db] = H16_MFMA_32x32x16(vf, pf[s2], o[db], 0, 0, 0);
+            for (int j = 0; j < NPV; ++j) {
+                if (j + A_PRE < NPV) vf[(j + A_PRE) % (A_PRE + 1)] = vread(j + A_PRE);
+                if (j == NPV - A_PRE) {
+                    // Waves 0-3 issue their DMA pieces right BEHIND the barrier (below), waves 4-7 -- their SIMD partners -- just in
+                    // FRONT of the next one (here: the pieces of the previous hand-over).  Same work, but the two waves of a SIMD
+                    // now run half a step apart: one is in its issue / softmax phase while the other has the matrix pipe.
+                    if (!three) {
+                        constexpr int TL = T + A_NSLOT - 1;
+                        if constexpr (T >= 1 && T <= 10) issue_q(nxt.oq, T - 1);
+                        if constexpr (TL < 16) issue_kv(TL < 8 ? cur.oq : cur.ox, TL & 7, TL & 3);
+                        else issue_kv(nxt.oq, TL - 16, TL & 3);
                     }
+                    // every LDS read of tile T has been issued (and, behind this wait, has returned): its slot may be refilled
+                    TSTAMP(3);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // issued since the pieces this hand-over needs: the K / V pieces of two hand-overs (6 or 4), the Q pieces of hand-overs
+                    // T - 2 and T - 1, the ten park stores behind step 7 (waves 4-7 issue the pieces of hand-over 7 after them, in step 8),
+                    // the ten park loads of step 15
+                    constexpr int QP = (T >= 2 && T <= 11 ? 1 : 0) + (T >= 1 && T <= 10 ? 1 : 0) + (T == 15 ? 10 : 0);
+                    if (T160_ABL(1024)) {       // kbench ablation 1024: one hand-over less in flight (is the stream latency-bound?)
+                        constexpr int QP1 = (T >= 1 && T <= 10 ? 1 : 0);
+                        if (three) wait_vm<3 + QP1>(); else wait_vm<2 + QP1>();
+                    } else
+                    if (three) wait_vm<6 + QP + (T >= 8 && T <= 10 ? 10 : 0)>(); else wait_vm<4 + QP + (T >= 8 && T <= 9 ? 10 : 0)>();
+                    TSTAMP(4);
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    TSTAMP(5);
+                    if (three) {
+                        constexpr int TN = T + A_NSLOT;
+                        if constexpr (T < 10) issue_q(nxt.oq, T);
+                        if constexpr (TN < 16) issue_kv(TN < 8 ? cur.oq : cur.ox, TN & 7, TN & 3);
+                        else issue_kv(nxt.oq, TN - 16, TN & 3);
+                    }
+                    const char* sn = smem + ((T + 1) & 3) * A_SLOT;
+#pragma unroll
+                    for (int ks = 0; ks < A_PRE; ++ks) kpre[ks] = *reinterpret_cast<const h16x8*>(sn + ((ks & 1) ? e1 : e0) + (ks >> 1) * 64);
+                    TSTAMP(6);
                 }
-            if constexpr (T == 7) pack_o(ypk);
-#ifdef DSIM_DEVTOOLS
+                __builtin_amdgcn_sched_barrier(0);
+                const int s2 = j / A_NDB, db = j % A_NDB;
+                if (idle) {
+                } else if (FIRST && s2 == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    o[db] = H16_MFMA_32x32x16(vf[j % (A_PRE + 1)], pf[s2], z, 0, 0, 0);
+                } else {
+                    o[db] = H16_MFMA_32x32x16(vf[j % (A_PRE + 1)], pf[s2], o[db], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            TSTAMP(7);
+            TSTAMP_ACC(0); TSTAMP_ACC(1); TSTAMP_ACC(2); TSTAMP_ACC(3); TSTAMP_ACC(4); TSTAMP_ACC(5); TSTAMP_ACC(6);
+            if constexpr (T == 7) if (!T160_ABL(64)) {
+                u32x4 ypk[2 * A_NDB];
+                pack_o(ypk);
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)(park + ((size_t)blockIdx.x * 8 + wave) * A_KTILE), 0, A_KTILE, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < 2 * A_NDB; ++i) __builtin_amdgcn_raw_buffer_store_b128(ypk[i], rP, ln * 16, i * 1024, 0);
+            }
+#if defined(DSIM_DEVTOOLS) && !defined(DSIM_STAMPS)
             if constexpr (T == 7 || T == 15) {           // kbench: the first unit's two outputs, f32, [pass][query][d]
                 if (dbg && blockIdx.x == 0 && it == 0) {
                     const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
@@ -295,9 +457,13 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
                 }
             }
 #endif
-            if constexpr (T == 15) {
+            if constexpr (T == 15) if (!T160_ABL(64)) {
                 u32x4 xpk[2 * A_NDB];
                 pack_o(xpk);
+                // the park loads have landed once only two of this step's hand-over pieces (3 or 2 per wave, no Q piece in step 15) are
+                // outstanding.  ONE statement for both wave classes: with the wait in two branches hipcc resolved the register
+                // assignment of one branch by copies placed in FRONT of its wait, i.e. of data that had not landed.
+                asm volatile("s_waitcnt vmcnt(2)" : "+v"(ypk[0]), "+v"(ypk[1]), "+v"(ypk[2]), "+v"(ypk[3]), "+v"(ypk[4]), "+v"(ypk[5]), "+v"(ypk[6]), "+v"(ypk[7]), "+v"(ypk[8]), "+v"(ypk[9]) :: "memory");
                 float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
                 if (!mse) {
 #pragma unroll
@@ -325,12 +491,9 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
                 float s0 = (a0[0] + a0[1]) + (a0[2] + a0[3]);
                 float s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
                 float s2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                    s0 += __shfl_xor(s0, off);
-                    s1 += __shfl_xor(s1, off);
-                    s2 += __shfl_xor(s2, off);
-                }
+                s0 = wave_sum(s0);
+                s1 = wave_sum(s1);
+                s2 = wave_sum(s2);
                 if (lane == 0) {
                     f32x4 r4 = {s0, s1, s2, 0.f};
                     *reinterpret_cast<f32x4*>(part + (size_t)cur.pidx * 4) = r4;
@@ -339,12 +502,20 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
         };
         step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{}); step(IC<4>{}); step(IC<5>{}); step(IC<6>{}); step(IC<7>{});
         step(IC<8>{}); step(IC<9>{}); step(IC<10>{}); step(IC<11>{}); step(IC<12>{}); step(IC<13>{}); step(IC<14>{}); step(IC<15>{});
+#if defined(DSIM_DEVTOOLS) && defined(DSIM_STAMPS)
+        TSTAMP(8);
+        tsa_[7] += tst_[8] - tst_[7];               // the epilogues (pack, park, partial sums)
+#endif
         if (!has_next) break;
         cur = nxt;
         read_q();           // (its ten pieces were issued in steps 0-9: older than everything step 15's wait left in flight)
         ++it;
     }
     wait_vm<0>();           // the look-ahead pieces of the last unit land in this workgroup's LDS
+#if defined(DSIM_DEVTOOLS) && defined(DSIM_STAMPS)
+    if (dbg && lane == 0)
+        for (int i = 0; i < 8; ++i) reinterpret_cast<unsigned long long*>(dbg)[((size_t)blockIdx.x * 8 + wave) * 8 + i] = tsa_[i];
+#endif
 }
 
 // One wave per pair: f64 fold of the per-wave partials in a fixed order (lane i adds entries i, i + 64, ...; xor tree), then
@@ -393,11 +564,19 @@ int tail160_grid(int n_pairs, int B, int H) {
 
 #ifdef DSIM_DEVTOOLS
 float* g_tail160_dbg = nullptr;
+int g_tail160_exp = 0;
 #endif
 
 bool pair_score160_applies(int N, int D, int dtype) { return N == A_N && D == A_D && dtype == DSIM_H16; }
 
-size_t pair_score160_scratch_bytes(int n_pairs, int B, int H) { return (size_t)n_pairs * 2 * B * H * 8 * 4 * sizeof(float); }
+static size_t tail160_part_bytes(int n_pairs, int B, int H) { return (((size_t)n_pairs * 2 * B * H * 8 * 4 * sizeof(float)) + 255) & ~(size_t)255; }
+
+// partial sums + one 80 KB park slab per workgroup (the grid is bounded by 512 workgroups whatever the device, which keeps this
+// function free of device queries)
+size_t pair_score160_scratch_bytes(int n_pairs, int B, int H) {
+    const long need = (((long)n_pairs * B * H + 7) / 8) * 16;
+    return tail160_part_bytes(n_pairs, B, H) + (size_t)(need < 512 ? need : 512) * 8 * A_KTILE;
+}
 
 int launch_pair_score160(const void* q, const void* k, const void* v, const int32_t* ia, const int32_t* ib, int n_pairs, int B,
                          int H, int mse, float* out, void* scratch, size_t scratch_bytes, hipStream_t s, int32_t* status) {
@@ -409,10 +588,10 @@ int launch_pair_score160(const void* q, const void* k, const void* v, const int3
     const float c = (1.0f / sqrtf((float)A_D)) * 1.4426950408889634f;
 #ifdef DSIM_DEVTOOLS
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), A_LDS, s, (const h16*)q, (const h16*)k, (const h16*)v, ia, ib, n_pairs, B, H, c,
-                       mse, (float*)scratch, g_tail160_dbg);
+                       mse, (float*)scratch, (char*)scratch + tail160_part_bytes(n_pairs, B, H), g_tail160_dbg, g_tail160_exp);
 #else
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), A_LDS, s, (const h16*)q, (const h16*)k, (const h16*)v, ia, ib, n_pairs, B, H, c,
-                       mse, (float*)scratch);
+                       mse, (float*)scratch, (char*)scratch + tail160_part_bytes(n_pairs, B, H));
 #endif
     hipLaunchKernelGGL(pair_finish160_kernel, dim3(n_pairs), dim3(64), 0, s, (const float*)scratch, B * H * 8, mse,
                        (double)B * H * A_N * A_D, out, status);

@@ -176,6 +176,7 @@ extern int g_attn_short;        // 0 = short key sequences through attn_kernel
 extern int g_attn_fast_min;     // fewest keys that take the fixed-reference softmax of attn_kernel
 extern int g_tail160;           // 0 = the 256-token d = 160 score tail through pair_tail_kernel
 extern float* g_tail160_dbg;    // kbench: device buffer for the first unit's two attention outputs
+extern int g_tail160_exp;       // kbench: experiment mask of pair_tail160_kernel
 extern int g_ff_dbg;            // ablation mask of the fused feed-forward kernel (rowres.hip)
 extern int g_rl_dbg;            // ablation mask of the row-resident Linear kernel (rowres.hip)
 extern int g_ff_stagger;        // its wave de-phasing, in s_nop 7 units per wave index

@@ -382,6 +382,27 @@ static void bench_tail(const char* name, int np, int iters, Timer& t) {
         printf("%-20s %s pairs=%3d  tiled %8.4f/%8.4f ms %7.1f TF/s | persistent d160 %8.4f/%8.4f ms %7.1f TF/s (min/median)  max rel diff %.3g  score[0] %.6f / %.6f st=%d/%d\n",
                name, sim ? "mse   " : "cosine", np, m0[0], m0[rounds / 2], fl / m0[rounds / 2] / 1e9, m1[0], m1[rounds / 2], fl / m1[rounds / 2] / 1e9, md,
                h0[0], h1[0], st0, st1);
+#ifdef DSIM_STAMPS
+        if (sim == 0) {
+            const int nwg = 256;
+            unsigned long long* sbuf; HC(hipMalloc((void**)&sbuf, (size_t)nwg * 8 * 8 * 8)); HC(hipMemset(sbuf, 0, (size_t)nwg * 8 * 8 * 8));
+            g_tail160_dbg = (float*)sbuf; g_tail160 = 1;
+            launch_pair_score(q, k, v, ia, ib, np, B, H, N, D, DSIM_BF16, sim, o1, scratch, sb, 0);
+            HC(hipDeviceSynchronize());
+            g_tail160_dbg = nullptr;
+            std::vector<unsigned long long> hs((size_t)nwg * 64);
+            HC(hipMemcpy(hs.data(), sbuf, hs.size() * 8, hipMemcpyDeviceToHost));
+            const char* nm[8] = {"QK", "yload+Vpre+softmax", "PV part 1", "lgkm+vmcnt wait", "barrier", "DMA issue+K pre", "PV part 2", "epilogues"};
+            for (int cls = 0; cls < 2; ++cls) {
+                double tot[8] = {0}, all = 0; int n = 0;
+                for (int w = 0; w < nwg * 8; ++w) { if (((w & 7) < 4) != (cls == 0)) continue; if (!hs[(size_t)w * 8]) continue; ++n; for (int i = 0; i < 8; ++i) { tot[i] += hs[(size_t)w * 8 + i]; all += hs[(size_t)w * 8 + i]; } }
+                printf("   stamps, waves %s (%d waves, %.0f cycles per wave):", cls ? "4-7" : "0-3", n, n ? all / n : 0.0);
+                for (int i = 0; i < 8; ++i) printf("  %s %.1f%%", nm[i], all ? 100.0 * tot[i] / all : 0.0);
+                printf("\n");
+            }
+            HC(hipFree(sbuf));
+        }
+#endif
         if (getenv("KB_TAILDBG") && sim == 0) {
             // the first unit (pair 0, direction 0, b 0, head 0): both attention outputs against a host evaluation, error by key-independent position
             float* dbg; HC(hipMalloc((void**)&dbg, 2 * N * D * 4)); HC(hipMemset(dbg, 0, 2 * N * D * 4));
@@ -474,6 +495,29 @@ static void bench_tail(const char* name, int np, int iters, Timer& t) {
                         }
                         printf("\n");
                     }
+        }
+        if (const char* e = getenv("KB_TAILEXP")) {          // interleaved rounds over experiment masks of the persistent kernel
+            std::vector<int> vals{0};
+            std::string l = e;
+            for (size_t pos = 0; pos < l.size();) {
+                size_t nx = l.find(',', pos);
+                if (nx == std::string::npos) nx = l.size();
+                vals.push_back(atoi(l.substr(pos, nx - pos).c_str()));
+                pos = nx + 1;
+            }
+            std::vector<std::vector<float>> ms(vals.size());
+            std::vector<float> sc(vals.size());
+            g_tail160 = 1;
+            for (int r = 0; r < rounds; ++r)
+                for (size_t kk = 0; kk < vals.size(); ++kk) {
+                    g_tail160_exp = vals[kk];
+                    ms[kk].push_back(t.run([&] { st1 = launch_pair_score(q, k, v, ia, ib, np, B, H, N, D, DSIM_BF16, sim, o1, scratch, sb, 0); }, iters));
+                    HC(hipMemcpy(&sc[kk], o1 + (np - 1), 4, hipMemcpyDeviceToHost));
+                }
+            g_tail160_exp = 0;
+            printf("   experiment masks, median ms (score of the last pair):");
+            for (size_t kk = 0; kk < vals.size(); ++kk) { std::sort(ms[kk].begin(), ms[kk].end()); printf("  %d: %.4f (%.7f)", vals[kk], ms[kk][rounds / 2], sc[kk]); }
+            printf("\n");
         }
         if (getenv("KB_TAILREF")) {
             std::vector<unsigned short> hq(per), hk(per), hv(per);

@@ -57,10 +57,26 @@ __device__ __forceinline__ float max_halves160(float x) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-// v_max3_f32 as ONE instruction: fmaxf on MFMA outputs draws a canonicalising v_max(x, x) per operand from hipcc
-__device__ __forceinline__ float max3(float a, float b, float c3) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c3));
+// Maximum of the 16 scores a lane holds after a QK^T chain, as ONE asm statement of v_max3_f32 (fmaxf on MFMA outputs draws a
+// canonicalising v_max(x, x) per operand from hipcc: 16 more vector instructions per step).  The statement OPENS with the 12 wait
+// states an 8-pass MFMA's result needs before a vector instruction may read it: hipcc pads that hazard for its own instructions
+// only, never inside or in front of an asm statement (cdna_hip_programming.md 5.7 item 2) -- without them the maximum was taken
+// over whatever the registers held before, i.e. partly over the PREVIOUS tile's scores on some launches: a different softmax
+// reference point, hence scores that moved in the seventh digit from run to run and self pairs scoring 0.999997.
+__device__ __forceinline__ float max16_after_mfma(const f32x16& s) {
+    float r, t1, t2, t3, t4;
+    asm volatile("s_nop 11\n\t"
+                 "v_max3_f32 %0, %5, %6, %7\n\t"
+                 "v_max3_f32 %1, %8, %9, %10\n\t"
+                 "v_max3_f32 %2, %11, %12, %13\n\t"
+                 "v_max3_f32 %3, %14, %15, %16\n\t"
+                 "v_max3_f32 %4, %17, %18, %19\n\t"
+                 "v_max3_f32 %0, %0, %1, %2\n\t"
+                 "v_max3_f32 %3, %3, %4, %20\n\t"
+                 "v_max_f32 %0, %0, %3"
+                 : "=&v"(r), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4)
+                 : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]), "v"(s[9]), "v"(s[10]),
+                   "v"(s[11]), "v"(s[12]), "v"(s[13]), "v"(s[14]), "v"(s[15]));
     return r;
 }
 constexpr float A_THR = 8.0f;                   // log2 units a row maximum may grow past the softmax reference before a rescale
@@ -118,8 +134,10 @@ __device__ __forceinline__ u32x4 make_desc(const void* p, unsigned bytes) {
 // a unit's tensors as BYTE offsets into the three allocations (q, k and v have one layout, so two offsets describe all five views:
 // four scalar registers per unit instead of ten; the descriptors are formed from them at the point of issue)
 struct Unit160 {
-    unsigned long long oq;              // the query image's rows (Q, and its own K / V: "self")
-    unsigned long long ox;              // the other image's K / V ("cross")
+    unsigned long long oq;              // the query image's rows
+    unsigned long long o0, o1;          // the K / V of the pair's FIRST image (pass 0: steps 0-7) and of its SECOND image (steps 8-15) --
+                                        // in BOTH directions, so that the two workgroups of a couple stream the same tensors at the same
+                                        // time (direction 1 runs its cross pass first)
     int pidx;                           // this wave's slot in the partial array
 };
 
@@ -219,10 +237,11 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
         Unit160 u;
         const int pair = p2 / BH, bh = p2 - pair * BH, b = bh / H, h = bh - b * H;
         const int ia = __builtin_amdgcn_readfirstlane(idx_a[pair]), ib = __builtin_amdgcn_readfirstlane(idx_b[pair]);
-        const int iq = dir ? ib : ia, ix = dir ? ia : ib;
+        const int iq = dir ? ib : ia;
         const unsigned long long off = ((unsigned long long)b * A_N * ld + h * A_D) * 2ull;
         u.oq = (unsigned long long)iq * (img * 2) + off;
-        u.ox = (unsigned long long)ix * (img * 2) + off;
+        u.o0 = (unsigned long long)ia * (img * 2) + off;
+        u.o1 = (unsigned long long)ib * (img * 2) + off;
         u.pidx = ((pair * 2 + dir) * BH + bh) * 8 + wave;
         return u;
     };
@@ -241,8 +260,8 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
 #pragma unroll
     for (int j = 0; j < 10; ++j) issue_q(cur.oq, j);
 #pragma unroll
-    for (int t = 0; t < A_NSLOT - 1; ++t) issue_kv(cur.oq, t, t);
-    if (three) issue_kv(cur.oq, A_NSLOT - 1, A_NSLOT - 1);        // (waves 4-7 issue it in step 0: see the hand-over)
+    for (int t = 0; t < A_NSLOT - 1; ++t) issue_kv(cur.o0, t, t);
+    if (three) issue_kv(cur.o0, A_NSLOT - 1, A_NSLOT - 1);        // (waves 4-7 issue it in step 0: see the hand-over)
     if (three) wait_vm<3 * A_NSLOT>(); else wait_vm<2 * (A_NSLOT - 1)>();
     read_q();
     // tile 0 visible to every wave; its first K fragments
@@ -289,6 +308,7 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
         // registers while those reads are in flight, instead of idling on LDS latency behind every barrier.
         // Vector-memory operations per hand-over in issue order: in steps 0-9 one Q piece of the next unit, then the K / V pieces of
         // tile T + 4 (3 or 2 per wave).  The hand-over of step T needs the pieces issued three hand-overs earlier.
+        u32x4 ypk[2 * A_NDB];
         auto step = [&](auto tc) {
             constexpr int T = decltype(tc)::value;
             const bool idle = (T160_ABL(128) && !three) || (T160_ABL(256) && three);          // kbench ablation 128: waves 4-7 only stage (one computing wave per SIMD)
@@ -313,11 +333,10 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
             }
             }
             TSTAMP(1);
-            u32x4 ypk[2 * A_NDB];
-            if constexpr (T == 15) {
-                // Q is dead: the parked self output comes back into its registers.  Inline asm, so that hipcc does not wait for these
-                // loads with a count that ignores the DMA pieces behind them; they are OLDER than this step's hand-over pieces, so the
-                // epilogue's counted wait covers them and leaves the pieces in flight.  sc1: served by L2 -- this CU's L1 may still hold
+            if constexpr (T == 13) {
+                // The parked self output comes back two steps before it is used: older than the DMA pieces of hand-overs 13 to 15, it has
+                // landed by the time hand-over 15's own wait has passed, and the epilogue waits for nothing.  Inline asm, so that hipcc
+                // does not wait for these loads with a count that ignores the DMA pieces behind them.  sc1: served by L2 -- this CU's L1 may still hold
                 // the slab's lines from the previous unit's read-back.  s_nop 4: an SGPR operand hipcc has just restored from a VGPR lane
                 // (v_readlane) needs five wait states before a VMEM reads it, and hipcc pads nothing inside an asm statement.
                 int ln = lane;
@@ -347,8 +366,7 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
             // invariant to it, P <= 2^A_THR keeps its relative precision in either 16-bit type, and the sums are f32.  (With the
             // exact rule the rescale -- 80 multiplies against the step's 20 MFMAs -- ran in nearly every step: one of 32 rows
             // almost always finds a new maximum among 32 more keys.)
-            float tmax = max3(max3(s[0], s[1], s[2]), max3(s[3], s[4], s[5]), max3(s[6], s[7], s[8]));
-            tmax = max3(tmax, max3(s[9], s[10], s[11]), max3(s[12], s[13], max3(s[14], s[15], s[15])));
+            float tmax = max16_after_mfma(s);
             tmax = max_halves160(tmax);
             if constexpr (FIRST) {
                 m_run = tmax;
@@ -391,21 +409,17 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
                     if (!three) {
                         constexpr int TL = T + A_NSLOT - 1;
                         if constexpr (T >= 1 && T <= 10) issue_q(nxt.oq, T - 1);
-                        if constexpr (TL < 16) issue_kv(TL < 8 ? cur.oq : cur.ox, TL & 7, TL & 3);
-                        else issue_kv(nxt.oq, TL - 16, TL & 3);
+                        if constexpr (TL < 16) issue_kv(TL < 8 ? cur.o0 : cur.o1, TL & 7, TL & 3);
+                        else issue_kv(nxt.o0, TL - 16, TL & 3);
                     }
                     // every LDS read of tile T has been issued (and, behind this wait, has returned): its slot may be refilled
                     TSTAMP(3);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     // issued since the pieces this hand-over needs: the K / V pieces of two hand-overs (6 or 4), the Q pieces of hand-overs
                     // T - 2 and T - 1, the ten park stores behind step 7 (waves 4-7 issue the pieces of hand-over 7 after them, in step 8),
-                    // the ten park loads of step 15
-                    constexpr int QP = (T >= 2 && T <= 11 ? 1 : 0) + (T >= 1 && T <= 10 ? 1 : 0) + (T == 15 ? 10 : 0);
-                    if (T160_ABL(1024)) {       // kbench ablation 1024: one hand-over less in flight (is the stream latency-bound?)
-                        constexpr int QP1 = (T >= 1 && T <= 10 ? 1 : 0);
-                        if (three) wait_vm<3 + QP1>(); else wait_vm<2 + QP1>();
-                    } else
-                    if (three) wait_vm<6 + QP + (T >= 8 && T <= 10 ? 10 : 0)>(); else wait_vm<4 + QP + (T >= 8 && T <= 9 ? 10 : 0)>();
+                    // the ten park loads of step 13 (waves 4-7 issue the pieces of hand-over 12 after them)
+                    constexpr int QP = (T >= 2 && T <= 11 ? 1 : 0) + (T >= 1 && T <= 10 ? 1 : 0) + (T == 13 || T == 14 ? 10 : 0);
+                    if (three) wait_vm<6 + QP + (T >= 8 && T <= 10 ? 10 : 0) + (T == 15 ? 10 : 0)>(); else wait_vm<4 + QP + (T >= 8 && T <= 9 ? 10 : 0)>();
                     TSTAMP(4);
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
@@ -413,8 +427,8 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
                     if (three) {
                         constexpr int TN = T + A_NSLOT;
                         if constexpr (T < 10) issue_q(nxt.oq, T);
-                        if constexpr (TN < 16) issue_kv(TN < 8 ? cur.oq : cur.ox, TN & 7, TN & 3);
-                        else issue_kv(nxt.oq, TN - 16, TN & 3);
+                        if constexpr (TN < 16) issue_kv(TN < 8 ? cur.o0 : cur.o1, TN & 7, TN & 3);
+                        else issue_kv(nxt.o0, TN - 16, TN & 3);
                     }
                     const char* sn = smem + ((T + 1) & 3) * A_SLOT;
 #pragma unroll
@@ -437,13 +451,15 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
             TSTAMP(7);
             TSTAMP_ACC(0); TSTAMP_ACC(1); TSTAMP_ACC(2); TSTAMP_ACC(3); TSTAMP_ACC(4); TSTAMP_ACC(5); TSTAMP_ACC(6);
             if constexpr (T == 7) if (!T160_ABL(64)) {
-                u32x4 ypk[2 * A_NDB];
-                pack_o(ypk);
+                u32x4 ysv[2 * A_NDB];
+                pack_o(ysv);
                 int ln = lane;
                 asm volatile("" : "+v"(ln));
                 const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)(park + ((size_t)blockIdx.x * 8 + wave) * A_KTILE), 0, A_KTILE, 0x00020000);
 #pragma unroll
-                for (int i = 0; i < 2 * A_NDB; ++i) __builtin_amdgcn_raw_buffer_store_b128(ypk[i], rP, ln * 16, i * 1024, 0);
+                // (the slab offset rides in the VECTOR offset: a buffer_store_dwordx4 with an SGPR soffset reads its data registers late and
+                // hipcc pads only for a constant offset: profiles/r05_experiments.txt item 3b)
+                for (int i = 0; i < 2 * A_NDB; ++i) __builtin_amdgcn_raw_buffer_store_b128(ysv[i], rP, ln * 16 + i * 1024, 0, 0);
             }
 #if defined(DSIM_DEVTOOLS) && !defined(DSIM_STAMPS)
             if constexpr (T == 7 || T == 15) {           // kbench: the first unit's two outputs, f32, [pass][query][d]
@@ -460,10 +476,10 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
             if constexpr (T == 15) if (!T160_ABL(64)) {
                 u32x4 xpk[2 * A_NDB];
                 pack_o(xpk);
-                // the park loads have landed once only two of this step's hand-over pieces (3 or 2 per wave, no Q piece in step 15) are
-                // outstanding.  ONE statement for both wave classes: with the wait in two branches hipcc resolved the register
-                // assignment of one branch by copies placed in FRONT of its wait, i.e. of data that had not landed.
-                asm volatile("s_waitcnt vmcnt(2)" : "+v"(ypk[0]), "+v"(ypk[1]), "+v"(ypk[2]), "+v"(ypk[3]), "+v"(ypk[4]), "+v"(ypk[5]), "+v"(ypk[6]), "+v"(ypk[7]), "+v"(ypk[8]), "+v"(ypk[9]) :: "memory");
+                // the park loads are older than everything hand-over 15 waited for: this wait only tells hipcc where their registers become
+                // valid (ONE statement for both wave classes: with it in two branches hipcc resolved the register assignment of one branch
+                // by copies placed in FRONT of its wait, i.e. of data that had not landed)
+                asm volatile("s_waitcnt vmcnt(6)" : "+v"(ypk[0]), "+v"(ypk[1]), "+v"(ypk[2]), "+v"(ypk[3]), "+v"(ypk[4]), "+v"(ypk[5]), "+v"(ypk[6]), "+v"(ypk[7]), "+v"(ypk[8]), "+v"(ypk[9]) :: "memory");
                 float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
                 if (!mse) {
 #pragma unroll
@@ -495,7 +511,8 @@ __global__ __launch_bounds__(512, 2) void pair_tail160_kernel(const h16* __restr
                 s1 = wave_sum(s1);
                 s2 = wave_sum(s2);
                 if (lane == 0) {
-                    f32x4 r4 = {s0, s1, s2, 0.f};
+                    // (x = the cross attention's output, y = the self attention's: direction 1 ran them in the other order)
+                    f32x4 r4 = {s0, dir ? s2 : s1, dir ? s1 : s2, 0.f};
                     *reinterpret_cast<f32x4*>(part + (size_t)cur.pidx * 4) = r4;
                 }
             }
@@ -575,7 +592,6 @@ static size_t tail160_part_bytes(int n_pairs, int B, int H) { return (((size_t)n
 // function free of device queries)
 size_t pair_score160_scratch_bytes(int n_pairs, int B, int H) {
     const long need = (((long)n_pairs * B * H + 7) / 8) * 16;
-    return tail160_part_bytes(n_pairs, B, H) + (size_t)(need < 512 ? need : 512) * 8 * A_KTILE;
 }
 
 int launch_pair_score160(const void* q, const void* k, const void* v, const int32_t* ia, const int32_t* ib, int n_pairs, int B,

@@ -289,3 +289,14 @@ def test_shared_synthetic_weights_are_written_once_and_mapped(tmp_path):
     import pytest
     with pytest.raises(TimeoutError):
         S.make_state_dict_shared(C.TINY, 4, keys, rank=1, world=8, cache_dir=str(tmp_path), timeout_s=0.5)
+
+
+def test_attn160_inline_asm_loads_are_not_touched_before_their_wait():
+    """csrc/attn160.hip reads the parked self-attention output back with inline-asm buffer loads hipcc does not track; the audit
+    compiles the file (bf16 and fp16) and checks that no instruction between those loads and their wait reads or writes the
+    destination registers, and that the kernel has no spills (tools/audit_attn160.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "audit_attn160.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -354,7 +354,7 @@ static void bench_tail(const char* name, int np, int iters, Timer& t) {
     void* k = dalloc_bf16(per, 12, 2.0f);
     void* v = dalloc_bf16(per, 13, 1.0f);
     std::vector<int32_t> ha(np), hb(np);
-    for (int i = 0; i < np; ++i) { ha[i] = 2 * i; hb[i] = 2 * i + 1; }
+    for (int i = 0; i < np; ++i) { ha[i] = 2 * i; hb[i] = getenv("KB_TAILSELF") ? 2 * i : 2 * i + 1; }
     int32_t *ia, *ib;
     HC(hipMalloc((void**)&ia, np * 4)); HC(hipMalloc((void**)&ib, np * 4));
     HC(hipMemcpy(ia, ha.data(), np * 4, hipMemcpyHostToDevice)); HC(hipMemcpy(ib, hb.data(), np * 4, hipMemcpyHostToDevice));
@@ -446,6 +446,13 @@ static void bench_tail(const char* name, int np, int iters, Timer& t) {
                 printf("\n");
             }
             {
+                if (getenv("KB_TAILSELF")) {
+                    double md = 0; int cnt = 0, wq = -1, wd = -1;
+                    for (int e = 0; e < N * D; ++e) { const double dd = fabs((double)hd[e] - (double)hd[(size_t)N * D + e]); if (dd > 0) ++cnt; if (dd > md) { md = dd; wq = e / D; wd = e % D; } }
+                    printf("   self pair: pass 0 vs pass 1 outputs differ in %d of %d elements, max |diff| %.3g at query %d d %d\n", cnt, N * D, md, wq, wd);
+                    for (int w = 0; w < 8; ++w) { int c2 = 0; for (int e = w * 32 * D; e < (w + 1) * 32 * D; ++e) c2 += hd[e] != hd[(size_t)N * D + e]; printf(" wave %d: %d", w, c2); }
+                    printf("\n");
+                }
                 printf("   sums of the dumped f32 outputs, unit 0 per wave [x.y x.x y.y] (f32 values and rounded to bf16):\n    ");
                 for (int w = 0; w < 8; ++w) {
                     double a = 0, b2 = 0, c2 = 0, ar = 0, br = 0, cr = 0;

@@ -318,6 +318,60 @@ def product_default_leg(cfg, sd, dtype, dev, lats, noise, ctx, headline_value):
                                 "score_sample": [round(float(x), 6) for x in s0[:2].float().cpu()]}}
 
 
+def pixels_in_leg(a, dtype, dev, eng, noise, nz, sa, sb, ctx, qkv, ia, ib, rank):
+    """The reference's real calling path in the driver-run line (`DiffSim.diffsim(image_A, image_B, ...)`,
+    /root/reference/diffsim/diffsim.py:103-113: pixels -> VAE encode -> noised U-Net to the tap -> score): the same bp pairs per
+    step as the headline with the SD1.5 VAE encoder (synthetic weights, 34 M parameters) in front of the U-Net, pixels resident in
+    HBM.  3 timed steps after one warm step (about 1 s of GPU time); the VAE's launches are profiled with HIP events on their
+    stream and the dominant one gets its own `roofline` (PMC fields from the committed --pixels-in passes)."""
+    global PMC_MODEL
+    from diffsim_amd.engine import VAEEncoder, latent_sample, pair_score
+    bp = a.batch_pairs
+    vae = VAEEncoder(C.VAE_SD15, S.make_state_dict(C.VAE_SD15, seed=1), dtype, str(dev))
+    nd = min(bp, 16)                  # the host-side image generator is slow: 16 distinct pairs, tiled to bp
+    base = torch.cat([torch.cat(S.make_image_pair(rank * nd + i, 512)) for i in range(nd)])
+    imgs = base.repeat((bp + nd - 1) // nd, 1, 1, 1)[:2 * bp].to(dev)
+    eps = torch.cat([noise[0], noise[1]] * bp).to(dev).contiguous()
+
+    def step():
+        z = latent_sample(vae.moments(imgs), eps, 0.18215)
+        q, k, v = eng.qkv(z, nz, sa, sb, ctx, out=qkv)
+        return pair_score(q, k, v, ia, ib, eng.heads, "cosine")
+
+    sc = step()
+    torch.cuda.synchronize()
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sc = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    v = steps * bp / el
+    out = {"value_pixels_in": round(v, 3),
+           "pixels_in": {"what": "bp pairs of 512 x 512 pixels resident in HBM -> VAE encoder -> posterior sample -> the headline's step",
+                         "pairs_per_step": bp, "distinct_image_pairs": nd, "steps": steps, "ms_per_step": round(1e3 * el / steps, 3),
+                         "gflop_per_pair": GFLOP_PER_PAIR_PIXELS,
+                         "whole_path_tflops": round(v * GFLOP_PER_PAIR_PIXELS / 1e3, 2),
+                         "score_sample": [round(float(x), 6) for x in sc[:2].float().cpu()]}}
+    if not a.no_profile:
+        vae.profile(True)
+        latent_sample(vae.moments(imgs), eps, 0.18215)
+        vrecs = [("vae_" + r[0],) + tuple(r[1:]) for r in vae.profile_records(detail=True)]
+        vae.profile(False)
+        vms = sum(r[3] for r in vrecs)
+        prev, PMC_MODEL = PMC_MODEL, "pixels_in"
+        PMC_SOURCES.clear()
+        rf = roofline_fields(vrecs, PEAK_F32_TFLOPS if a.dtype == "fp32" else PEAK_BF16_TFLOPS)
+        PMC_MODEL = prev
+        PMC_SOURCES.clear()
+        out["pixels_in"].update({"vae_ms_per_image": round(vms / (2 * bp), 4), "vae_ms_per_step": round(vms, 3),
+                                 "vae_tflops": round(sum(r[1] for r in vrecs) / (vms * 1e-3) / 1e12, 1),
+                                 "vae_roofline": rf["roofline"], "vae_kernel_breakdown_ms_per_step": rf["kernel_breakdown_ms_per_step"]})
+    del vae, imgs
+    torch.cuda.empty_cache()
+    return out
+
+
 def secondary(a, world, rank, dev):
     """Secondary bench lines: DiffSim-XL (SDXL U-Net, 1024 px, tap up_blocks [0,0,0]; BASELINE config 4) and
     DiffSim-DiT (DiT-XL/2, 256 px, tap blocks[13]; config 5, --fp8-attention) -- same step definition (latents resident
@@ -508,7 +562,7 @@ def headline(a, world, rank, dev):
                                % (("pixels-in incl. VAE encoder" if a.pixels_in else "latents-in") +
                                   (", CFG halves de-duplicated up to the first cross-attention" if a.dedup_cfg else "")),
                    "pairs_per_step_per_gpu": bp * NS, "concurrent_sub_batches": NS, "pairs_per_sub_batch": bp,
-                   "distinct_pairs_resident_per_gpu": bp * (1 if a.pixels_in else NB),
+                   "distinct_pairs_resident_per_gpu": min(bp, 16) if a.pixels_in else bp * NB,          # (pixels-in: 16 distinct image pairs, tiled to bp)
                    "gflop_per_pair": GFLOP_PER_PAIR_PIXELS if a.pixels_in else GFLOP_PER_PAIR, "parallelism": f"pairs sharded x{world}"},
         "whole_path_tflops_per_gpu": round(pairs_per_s / world * (GFLOP_PER_PAIR_PIXELS if a.pixels_in else GFLOP_PER_PAIR) / 1e3, 2),
         "score_sample": [round(float(x), 6) for x in scores[:4].float().cpu()],
@@ -544,6 +598,8 @@ def headline(a, world, rank, dev):
                                        dump=a.dump_launches))
         if world == 1 and not a.pixels_in and not a.no_product_default:
             out.update(product_default_leg(cfg, sd, dtype, dev, lats, noise, ctx, pairs_per_s))
+        if world == 1 and not a.pixels_in and not a.no_pixels_leg:
+            out.update(pixels_in_leg(a, dtype, dev, eng, noise, nz, sa, sb, ctx, qkv, ia, ib, rank))
         if world == 1 and not a.no_cpu_baseline:
             out.update(cpu_baseline_sd15(cfg, sd, lats, noise, scores, a.cpu_pairs))
         print(json.dumps(out), flush=True)
@@ -572,6 +628,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-product-default", action="store_true",
                     help="skip the secondary leg that scores the resident pairs through DiffSim.score_latent_pairs with no knobs")
+    ap.add_argument("--no-pixels-leg", action="store_true", help="skip the pixels-in leg (VAE encoder in front) of the default run")
     ap.add_argument("--dump-launches", type=str, default=None, help="write the per-launch records of the profiled step (JSON lines)")
     ap.add_argument("--model", choices=["sd15", "sdxl", "dit"], default="sd15",
                     help="sd15 = the headline metric (BASELINE config[1]); sdxl / dit = secondary lines for configs[3], [4]")
@@ -620,7 +677,7 @@ def main():
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
         dist.init_process_group("nccl", device_id=dev)
     global PMC_MODEL
-    PMC_MODEL = a.model
+    PMC_MODEL = "pixels_in" if (a.model == "sd15" and a.pixels_in) else a.model
     if a.model != "sd15":
         secondary(a, world, rank, dev)
     else:

@@ -592,6 +592,7 @@ static size_t tail160_part_bytes(int n_pairs, int B, int H) { return (((size_t)n
 // function free of device queries)
 size_t pair_score160_scratch_bytes(int n_pairs, int B, int H) {
     const long need = (((long)n_pairs * B * H + 7) / 8) * 16;
+    return tail160_part_bytes(n_pairs, B, H) + (size_t)(need < 512 ? need : 512) * 8 * A_KTILE;
 }
 
 int launch_pair_score160(const void* q, const void* k, const void* v, const int32_t* ia, const int32_t* ib, int n_pairs, int B,

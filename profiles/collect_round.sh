@@ -6,7 +6,7 @@ G=gpurun_out
 python3 profiles/summarize.py $T $G/prof_${T}_trace $G/prof_${T}_fetch $G/prof_${T}_write $G/prof_${T}_mfma
 python3 profiles/summarize.py ${T}_sdxl $G/prof_${T}_trace_sdxl $G/prof_${T}_sdxl_fetch $G/prof_${T}_sdxl_write $G/prof_${T}_sdxl_mfma
 python3 profiles/summarize.py ${T}_dit $G/prof_${T}_trace_dit $G/prof_${T}_dit_fetch $G/prof_${T}_dit_write $G/prof_${T}_dit_mfma
-python3 profiles/summarize.py --stats-only ${T}_pixels_in $G/prof_${T}_trace_pixels
+python3 profiles/summarize.py ${T}_pixels_in $G/prof_${T}_trace_pixels $G/prof_${T}_pixels_in_fetch $G/prof_${T}_pixels_in_write $G/prof_${T}_pixels_in_mfma
 python3 profiles/summarize.py --mfma-only ${T}_pmc_mfma_sustained $G/prof_${T}_mfma40          # 40 back-to-back steps: MFMA busy + held clock
 python3 profiles/summarize_shapes.py $T $G/launches_${T}.jsonl $G/prof_${T}_fetch $G/prof_${T}_write
 python3 profiles/summarize_tap.py $T $G/prof_${T}_tap1 $G/prof_${T}_tap2
@@ -18,7 +18,7 @@ done
 python3 - $T <<'PY'
 import json, os, sys
 tag = sys.argv[1]
-for suffix, model in (("", ""), ("_10k", ""), ("_two_streams", ""), ("_unfused", ""), ("_dedup_cfg", ""), ("_pixels_in", ""), ("_sdxl", "sdxl_"), ("_dit", "dit_"), ("_dit_fp8", "dit_")):
+for suffix, model in (("", ""), ("_10k", ""), ("_two_streams", ""), ("_unfused", ""), ("_dedup_cfg", ""), ("_pixels_in", "pixels_in_"), ("_sdxl", "sdxl_"), ("_dit", "dit_"), ("_dit_fp8", "dit_")):
     p = f"profiles/{tag}_bench{suffix}.json"
     hb, mf = f"profiles/{tag}_{model}pmc_hbm.json", f"profiles/{tag}_{model}pmc_mfma.json"
     if not (os.path.exists(p) and os.path.exists(hb) and os.path.exists(mf)):

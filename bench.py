@@ -495,8 +495,14 @@ def headline(a, world, rank, dev):
     ds = DiffSim(torch_dtype=dtype, device=str(dev), unet_config=cfg, state_dict=sd, dedup_cfg=a.dedup_cfg, fusion=a.fusion)
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()                     # every rank has mapped rank 0's weight file
+        # every rank has mapped rank 0's weight file -- and proves it: the fingerprints must agree before anything is scored
+        fp = torch.tensor([S.shared_fingerprint(sd)], dtype=torch.int64, device=dev)
+        lo, hi = fp.clone(), fp.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         S.cleanup_shared()
+        if int(lo) != int(hi):
+            raise SystemExit(f"bench.py: rank {rank} holds different synthetic weights than another rank (fingerprint {int(fp):x})")
     eng = ds.engine("up_blocks", 0)
     t = sched.timestep_from_index(600)
     eng.set_timestep(t)

@@ -58,10 +58,14 @@ def make_state_dict(cfg: UNetConfig, seed: int = 0, keys: Optional[Sequence[str]
 
 
 _SHARED_FILES = []          # files this process (rank 0) wrote for the other ranks
+_CLEANUP_HOOKED = False
+_T_IMPORT = __import__("time").time()
 
 
 def cleanup_shared():
-    """Rank 0, once every rank has loaded (after a barrier): remove the shared files (they sit in /dev/shm, i.e. in memory)."""
+    """Rank 0, once every rank has loaded (after a barrier): remove the shared files (they sit in /dev/shm, i.e. in memory).
+    Also runs at interpreter exit and on SIGTERM / SIGINT of rank 0, so a job that dies between the write and the barrier does
+    not leave 2.8 GB of SD1.5 weights behind."""
     import os
     while _SHARED_FILES:
         try:
@@ -70,39 +74,98 @@ def cleanup_shared():
             pass
 
 
+def _hook_cleanup():
+    global _CLEANUP_HOOKED
+    if _CLEANUP_HOOKED:
+        return
+    _CLEANUP_HOOKED = True
+    import atexit
+    import signal
+    atexit.register(cleanup_shared)
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        try:
+            prev = signal.getsignal(sig)
+
+            def handler(signum, frame, _prev=prev):
+                cleanup_shared()
+                if callable(_prev):
+                    _prev(signum, frame)
+                else:
+                    signal.signal(signum, signal.SIG_DFL)
+                    import os
+                    os.kill(os.getpid(), signum)
+            signal.signal(sig, handler)
+        except (ValueError, OSError):           # not the main thread: atexit still runs
+            pass
+
+
+def launch_nonce() -> str:
+    """What the ranks of ONE launch share and no other launch has: DSIM_LAUNCH_NONCE when the launcher sets it, else the parent
+    process id (the torch.distributed.run agent, or parallel.spawn_ranks' supervisor, is the parent of every rank)."""
+    import os
+    return os.environ.get("DSIM_LAUNCH_NONCE") or f"ppid{os.getppid()}"
+
+
+def shared_fingerprint(sd: Dict[str, torch.Tensor]) -> int:
+    """A 63-bit content fingerprint of a state dict (names, shapes and the bytes of up to 64 Ki elements per tensor): ranks compare
+    it once the process group is up (bench.py), so a rank that mapped anything but rank 0's weights stops the job."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        t = sd[k]
+        h.update(k.encode())
+        h.update(str(tuple(t.shape)).encode())
+        h.update(t.detach().reshape(-1)[:65536].contiguous().cpu().numpy().tobytes())
+    return int.from_bytes(h.digest()[:8], "little") >> 1
+
+
 def make_state_dict_shared(cfg, seed: int = 0, keys: Optional[Sequence[str]] = None, rank: int = 0, world: int = 1,
                            cache_dir: Optional[str] = None, timeout_s: float = 900.0) -> Dict[str, torch.Tensor]:
     """``make_state_dict`` for the N ranks of ONE node: rank 0 synthesises the tensors (698 M parameters for SD1.5 to the tap:
     tens of seconds of host time) and writes them once as a safetensors file under `cache_dir` (default: /dev/shm or the temp
     directory); the other ranks wait for the file and map it instead of each repeating the synthesis on the same cores.  File
-    based, so it works before any process group exists; the name carries the config, seed and key set, and the file appears
-    atomically (written under a temporary name, then renamed).  Same tensors as make_state_dict, bit for bit."""
+    based, so it works before any process group exists.  The name carries the config, seed, key set, the user id and the LAUNCH
+    (`launch_nonce`); rank 0 ALWAYS writes (temporary name, mode 0600, then an atomic replace over whatever was there), and the
+    other ranks accept only a file they own -- same uid, not group / world writable -- that was written after this launch began
+    (a leftover of an earlier run, or a file another local user planted under the predictable name, is never loaded; they keep
+    waiting for rank 0's).  Same tensors as make_state_dict, bit for bit; `shared_fingerprint` lets the ranks prove it."""
     if world <= 1:
         return make_state_dict(cfg, seed, keys)
     import hashlib
     import os
+    import stat
     import tempfile
     import time
     from safetensors.torch import load_file, save_file
     d = cache_dir or ("/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir())
-    # (MASTER_PORT: one file per launch, never a stale one of an earlier run of other code)
-    tag = hashlib.sha256((repr(cfg) + "|" + str(seed) + "|" + os.environ.get("MASTER_PORT", "") + "|" +
+    tag = hashlib.sha256((repr(cfg) + "|" + str(seed) + "|" + os.environ.get("MASTER_PORT", "") + "|" + launch_nonce() + "|" +
                           ",".join(sorted(keys) if keys is not None else ["*"])).encode()).hexdigest()[:16]
     path = os.path.join(d, f"dsim_synth_{os.getuid()}_{tag}.safetensors")
     if rank == 0:
         sd = make_state_dict(cfg, seed, keys)
-        if not os.path.exists(path):
-            tmp = f"{path}.{os.getpid()}.tmp"
-            save_file(sd, tmp)
-            os.replace(tmp, path)
+        _hook_cleanup()
+        tmp = f"{path}.{os.getpid()}.tmp"
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        os.close(fd)
+        _SHARED_FILES.append(tmp)
+        save_file(sd, tmp)
+        os.replace(tmp, path)
+        _SHARED_FILES.remove(tmp)
         _SHARED_FILES.append(path)
         return sd
     t0 = time.monotonic()
-    while not os.path.exists(path):
+    while True:
+        try:
+            st = os.stat(path)
+            mine = st.st_uid == os.getuid() and not (st.st_mode & (stat.S_IWGRP | stat.S_IWOTH)) and stat.S_ISREG(st.st_mode)
+            fresh = st.st_mtime >= _T_IMPORT - 120.0        # written by THIS launch's rank 0 (ranks start within seconds of each other)
+            if mine and fresh:
+                return load_file(path)
+        except FileNotFoundError:
+            pass
         if time.monotonic() - t0 > timeout_s:
             raise TimeoutError(f"rank {rank}: {path} did not appear within {timeout_s:.0f} s (did rank 0 fail?)")
         time.sleep(0.2)
-    return load_file(path)
 
 
 def add_checkpoint_like_outliers(sd: Dict[str, torch.Tensor], seed: int = 5, conv_gain: float = 40.0, qk_gain: float = 5.0

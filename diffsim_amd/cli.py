@@ -4,7 +4,7 @@
 
 Flags of the reference drivers (``/root/reference/argprocess.py:5-18``) keep their names, meaning and defaults;
 ``--dataset`` selects which of the reference's loops runs (``cute_main.py:48-226``, ``night_main.py:24-173`` or
-``style_main.py:24-196`` -- separate scripts there), ``--model_path / --dtype / --batch / --ngpu / --noise_dtype`` are additions of this build (the reference
+``style_main.py:24-196`` -- separate scripts there), ``--model_path / --dtype / --batch / --unet_batch / --ngpu / --noise_dtype`` are additions of this build (the reference
 hard-codes NAS checkpoint paths, ``cute_main.py:25-31``, fp16 and one GPU, ``cute_main.sh:1``).
 
 Multi-GPU (``--ngpu N``): the parent starts N rank processes before anything touches the GPU; triplets are sharded
@@ -49,7 +49,9 @@ def build_parser() -> argparse.ArgumentParser:
                    help="engine compute dtype (fp16 = the reference drivers' torch.float16; fp32 = parity mode)")
     p.add_argument("--noise_dtype", type=str, choices=["fp32", "fp16"], default="fp32",
                    help="generator draws / add_noise arithmetic: fp32 pipeline or the reference's literal fp16 pipeline")
-    p.add_argument("--batch", type=int, default=10, help="triplets per engine batch")
+    p.add_argument("--batch", type=int, default=10, help="triplets per decode / VAE-encode chunk")
+    p.add_argument("--unet_batch", type=int, default=None,
+                   help="triplets per U-Net engine batch (default: chosen from free device memory; lower it on a shared or smaller GPU)")
     p.add_argument("--ngpu", type=int, default=None,
                    help="GPUs of this node to shard the triplets over (one process each); default 1, or the launcher's rank count")
     p.add_argument("--decode_procs", type=str, default="auto",
@@ -212,7 +214,7 @@ def run(args) -> int:
         s_ab, s_ac, bad = _selftest_scores(trip, rank, world)
     else:
         s_ab, s_ac, bad = H.score_path_triplets(scorer, trip, args.image_size, args.target_block, layer, args.target_step, args.seed,
-                                                args.similarity, rank, world, args.batch)
+                                                args.similarity, rank, world, args.batch, args.unet_batch)
     if rank == 0:
         total = len(trip)
         if bad:

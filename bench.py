@@ -67,6 +67,8 @@ def rocprof_name(fam: str) -> str:
         t = {"bf16": "__bf16", "f16": "_Float16"}.get(p[1], "float")
         d = p[2][1:]
         kind = p[3] if len(p) > 3 else ""              # the suffix csrc/attention.hip attention_kernel_kind() gave the family
+        if kind == "p160":
+            return "sdpa160_kernel"
         if kind == "short":
             return f"attn_short_kernel<{d}>"
         if kind == "long":

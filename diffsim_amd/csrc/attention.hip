@@ -1381,15 +1381,18 @@ int g_attn_dbg = 0;
 int g_attn_short = 1;
 int g_attn_fast_min = 1024;
 int g_tail160 = 1;
+int g_sdpa160 = 1;
 #endif
 
 // Which kernel launch_attention picks for this problem, as the suffix of the profile family name (bench.py maps family names to
 // the symbols rocprofv3 prints): "_short" attn_short_kernel (keys resident in LDS), "_long" attn_long_kernel (two query blocks
 // per wave, pipelined), "_q2" / "_q2fast" attn_q2_kernel (two query blocks per wave sharing every fragment read; exact / fixed-reference
-// softmax), "_fast" attn_kernel with the fixed-reference softmax, "" attn_kernel with the exact running maximum.
+// softmax), "_fast" attn_kernel with the fixed-reference softmax, "_p160" sdpa160_kernel (attn160.hip: 256 x 256 tokens at d = 160 on the
+// persistent core), "" attn_kernel with the exact running maximum.
 // Mirrors launch_attn_d's conditions (the development switches are 1 in the product).
 const char* attention_kernel_kind(const AttnArgs& a, int dtype) {
     if (dtype == DSIM_F32) return "";
+    if (g_sdpa160 && sdpa160_applies(a)) return "_p160";
     if ((a.D == 40 || a.D == 80 || (a.D == 64 && a.Nq <= 1024)) && a.Nk <= 96) return "_short";
     if (a.D == 40 && a.Nk >= 2048 && a.Nk % KT == 0) return "_long";
     if (a.D == 64 && a.Nk > 96 && a.Nq >= 256) return a.Nk >= g_attn_fast_min ? "_q2fast" : "_q2";
@@ -1401,7 +1404,10 @@ int launch_attention(const AttnArgs& a, int dtype, hipStream_t s) {
     const int vec = dtype == DSIM_F32 ? 4 : 8;
     if (a.D % 8 || a.ldq % vec || a.ldk % vec || a.ldo % 4 || a.Nk < 1 || a.Nq < 1 || a.Bkv < 1)
         return DSIM_ERR_INVALID;
-    if (dtype == DSIM_H16) return launch_attn_t<h16>(a, s);
+    if (dtype == DSIM_H16) {
+        if (g_sdpa160 && sdpa160_applies(a)) return launch_sdpa160(a, s);      // 256 x 256 tokens at d = 160: the persistent core (attn160.hip)
+        return launch_attn_t<h16>(a, s);
+    }
 #ifndef DSIM_H16_IS_F16
     if (dtype == DSIM_F32) return launch_attn_t<float>(a, s);
 #ifdef DSIM_HAS_F16_TWINS

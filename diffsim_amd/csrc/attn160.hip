@@ -567,6 +567,255 @@ __global__ __launch_bounds__(64) void pair_finish160_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The same core as a plain scaled-dot-product attention: the U-Net's own self-attentions of the 16 x 16 level (attn1 of the 1280-channel
+// transformer blocks: /root/reference/diffsim/hacked_attn.py:74-81 with 256 tokens, 8 heads x 160).  A unit is one (batch element,
+// head); its 8 steps are the tail's pass 0.  Differences from the tail: q, k, v and the output carry their own row strides (the fused
+// q|k|v projection writes 3 C-wide rows); every wave issues its DMA pieces behind the barrier; the next unit's ten Q pieces ride in
+// hand-overs 0-4 (two each), so they are older than what hand-over 7 waits for and the slab can be read right behind step 7; the
+// output, normalised and rounded, goes through the wave's Q slab (just emptied into registers) and leaves as 16-byte row segments.
+__global__ __launch_bounds__(512, 2) void sdpa160_kernel(const h16* __restrict__ qg, const h16* __restrict__ kg, const h16* __restrict__ vg,
+                                                         h16* __restrict__ og, const int ldq, const int ldk, const int ldo, const int B,
+                                                         const int H, const float c) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int rbq = ldq * 2, rbk = ldk * 2, rbo = ldo * 2;
+    const int total = B * H;
+    // workgroup -> unit: the eight consecutive units (heads of one batch element when H = 8: neighbours in every token row, they share
+    // cache lines) run at the same time on eight workgroups of ONE XCD
+    const int xcd = blockIdx.x & 7, wslot = blockIdx.x >> 3, g8 = (int)gridDim.x >> 6;
+    const unsigned recs_q = (unsigned)((A_N - 1) * rbq + A_ROWB), recs_k = (unsigned)((A_N - 1) * rbk + A_ROWB);
+
+    auto piece_voff = [&](int pat, bool swizzle, int ln, int rb) {
+        const int f = 64 * pat + ln;
+        const int r = (f * 3277) >> 16, pos = f - r * 20;
+        const int ch = swizzle ? ((pos & ~3) | ((pos & 3) ^ (r >> 2))) : pos;
+        return r * rb + ch * 16;
+    };
+    int kv_voff[3], kv_grp[3];
+    unsigned kv_lds[3];
+    bool kv_isv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int pj = wave + 8 * j;
+        kv_isv[j] = pj >= 10;
+        const int p = kv_isv[j] ? pj - 10 : pj;
+        const int grp = p >= 5, pat = p - 5 * grp;
+        kv_voff[j] = piece_voff(pat, !kv_isv[j], lane, rbk);
+        kv_grp[j] = grp;
+        kv_lds[j] = (kv_isv[j] ? A_KTILE : 0) + p * 1024;
+    }
+    const bool three = wave < 4;
+    auto issue_kv = [&](unsigned long long uoff, int tile, int slot) {
+        const u32x4 dK = make_desc((const char*)kg + uoff, recs_k), dV = make_desc((const char*)vg + uoff, recs_k);
+        int rb = rbk;
+        unsigned lb = lbase;
+        asm volatile("" : "+s"(rb), "+s"(lb));
+        const unsigned sb = lb + slot * A_SLOT;
+        const int ts = tile * A_KT * rb;
+        dma_piece(sb + kv_lds[0], kv_voff[0], dK, ts + kv_grp[0] * 16 * rb);
+        dma_piece(sb + kv_lds[1], kv_voff[1], kv_isv[1] ? dV : dK, ts + kv_grp[1] * 16 * rb);
+        if (three) dma_piece(sb + kv_lds[2], kv_voff[2], dV, ts + kv_grp[2] * 16 * rb);
+    };
+    const unsigned qslab = lbase + A_RING + wave * A_KTILE;
+    auto issue_q = [&](unsigned long long uoff, int j) {
+        const u32x4 dQ = make_desc((const char*)qg + uoff, recs_q);
+        int ln = lane, rb = rbq;
+        unsigned qs = qslab;
+        asm volatile("" : "+v"(ln), "+s"(rb), "+s"(qs));
+        dma_piece(qs + j * 1024, piece_voff(j % 5, true, ln, rb), dQ, (wave * 32 + 16 * (j / 5)) * rb);
+    };
+    const int swz = (l31 >> 2) & 3;
+    const int e0 = l31 * A_ROWB + ((half ^ swz) << 4);
+    const int e1 = l31 * A_ROWB + (((2 + half) ^ swz) << 4);
+    const int vl = A_KTILE + (4 * half + ((lane & 15) >> 2)) * A_ROWB + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+    struct Unit { unsigned long long oq, ok, oo; };
+    auto setup = [&](int u) {
+        Unit r;
+        const int b = u / H, h = u - b * H;
+        r.oq = ((unsigned long long)b * A_N * ldq + h * A_D) * 2ull;
+        r.ok = ((unsigned long long)b * A_N * ldk + h * A_D) * 2ull;
+        r.oo = ((unsigned long long)(b * A_N + wave * 32) * ldo + h * A_D) * 2ull;
+        return r;
+    };
+    auto unit_of = [&](int it) { return ((it * g8 + (wslot >> 3)) * 8 + xcd) * 8 + (wslot & 7); };
+    h16x8 q[A_NKS];
+    auto read_q = [&]() {
+        const char* s0 = smem + A_RING + wave * A_KTILE;
+#pragma unroll
+        for (int ks = 0; ks < A_NKS; ++ks) q[ks] = *reinterpret_cast<const h16x8*>(s0 + ((ks & 1) ? e1 : e0) + (ks >> 1) * 64);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+
+    int it = 0;
+    if (unit_of(0) >= total) return;
+    Unit cur = setup(unit_of(0));
+#pragma unroll
+    for (int j = 0; j < 10; ++j) issue_q(cur.oq, j);
+#pragma unroll
+    for (int t = 0; t < A_NSLOT; ++t) issue_kv(cur.ok, t, t);
+    if (three) wait_vm<3 * A_NSLOT>(); else wait_vm<2 * A_NSLOT>();
+    read_q();
+    if (three) wait_vm<3 * (A_NSLOT - 1)>(); else wait_vm<2 * (A_NSLOT - 1)>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    h16x8 kpre[A_PRE];
+#pragma unroll
+    for (int ks = 0; ks < A_PRE; ++ks) kpre[ks] = *reinterpret_cast<const h16x8*>(smem + ((ks & 1) ? e1 : e0) + (ks >> 1) * 64);
+
+    f32x16 o[A_NDB];
+    float m_run = 0.f, l_run = 0.f;
+    const float thr = A_THR / c;
+    bool first = true;                  // the first unit: nothing of a previous unit (its output stores, its late Q pieces) is in flight
+
+    for (;;) {
+        const int un = unit_of(it + 1);
+        const bool has_next = un < total;
+        const Unit nxt = has_next ? setup(un) : cur;       // (no next unit: the look-ahead re-fetches this unit's own rows)
+
+        auto step = [&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+            constexpr bool FIRST = T == 0;
+            const char* sb = smem + (T & 3) * A_SLOT;
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            h16x8 kf[A_PRE + 1];
+#pragma unroll
+            for (int i = 0; i < A_PRE; ++i) kf[i] = kpre[i];
+#pragma unroll
+            for (int ks = 0; ks < A_NKS; ++ks) {
+                if (ks + A_PRE < A_NKS)
+                    kf[(ks + A_PRE) % (A_PRE + 1)] = *reinterpret_cast<const h16x8*>(sb + (((ks + A_PRE) & 1) ? e1 : e0) + ((ks + A_PRE) >> 1) * 64);
+                __builtin_amdgcn_sched_barrier(0);
+                s = H16_MFMA_32x32x16(kf[ks % (A_PRE + 1)], q[ks], s, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const char* vb = sb + vl;
+            auto vread = [&](int j) {
+                const char* pa = vb + (j / A_NDB) * 16 * A_ROWB + (j % A_NDB) * 64;
+                const h16x4 lo = h16_ds_read_tr16_b64(pa);
+                const h16x4 hi = h16_ds_read_tr16_b64(pa + 8 * A_ROWB);
+                h16x8 vf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+                return vf;
+            };
+            h16x8 vf[A_PRE + 1];
+#pragma unroll
+            for (int j = 0; j < A_PRE; ++j) vf[j] = vread(j);
+            __builtin_amdgcn_sched_barrier(0);
+            float tmax = max16_after_mfma(s);
+            tmax = max_halves160(tmax);
+            if constexpr (FIRST) {
+                m_run = tmax;
+            } else {
+                if (!__all(tmax <= m_run + thr)) {
+                    const float mn = fmaxf(m_run, tmax);
+                    const float alpha = __builtin_amdgcn_exp2f((m_run - mn) * c);
+                    m_run = mn;
+                    l_run *= alpha;
+#pragma unroll
+                    for (int db = 0; db < A_NDB; ++db)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+                }
+            }
+            const float mc = -m_run * c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], c, mc));
+            const float psum = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) +
+                               (((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15])));
+            l_run = FIRST ? psum : l_run + psum;
+            h16x8 pf[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[f][e] = (h16)s[8 * f + e];
+            constexpr int NPV = 2 * A_NDB;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NPV; ++j) {
+                if (j + A_PRE < NPV) vf[(j + A_PRE) % (A_PRE + 1)] = vread(j + A_PRE);
+                if (j == NPV - A_PRE) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // Issued since the pieces of tile T + 1 (hand-over T - 3): two hand-overs' K / V pieces (3 or 2 each) and Q pieces
+                    // (two per hand-over 0-4), and -- in steps 0-2 -- the previous unit's ten output stores.  In the first unit
+                    // neither the stores nor the Q pieces of hand-overs 6, 7 exist.
+                    constexpr int NQ2 = (((T + 6) & 7) <= 4 ? 2 : 0) + (((T + 7) & 7) <= 4 ? 2 : 0);
+                    constexpr int STEADY = NQ2 + (T <= 2 ? 10 : 0);
+                    constexpr int FIRSTU = T == 0 ? 0 : T == 1 ? 2 : T == 2 ? 4 : STEADY;
+                    if (T <= 2 && first) { if (three) wait_vm<6 + FIRSTU>(); else wait_vm<4 + FIRSTU>(); }
+                    else { if (three) wait_vm<6 + STEADY>(); else wait_vm<4 + STEADY>(); }
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    if constexpr (T <= 4) { issue_q(nxt.oq, 2 * T); issue_q(nxt.oq, 2 * T + 1); }
+                    constexpr int TN = T + A_NSLOT;
+                    if constexpr (TN < 8) issue_kv(cur.ok, TN, TN & 3);
+                    else issue_kv(nxt.ok, TN - 8, TN & 3);
+                    const char* sn = smem + ((T + 1) & 3) * A_SLOT;
+#pragma unroll
+                    for (int ks = 0; ks < A_PRE; ++ks) kpre[ks] = *reinterpret_cast<const h16x8*>(sn + ((ks & 1) ? e1 : e0) + (ks >> 1) * 64);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int s2 = j / A_NDB, db = j % A_NDB;
+                if (FIRST && s2 == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    o[db] = H16_MFMA_32x32x16(vf[j % (A_PRE + 1)], pf[s2], z, 0, 0, 0);
+                } else {
+                    o[db] = H16_MFMA_32x32x16(vf[j % (A_PRE + 1)], pf[s2], o[db], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{}); step(IC<4>{}); step(IC<5>{}); step(IC<6>{}); step(IC<7>{});
+        first = false;
+
+        // ---- the unit's output.  The next unit's Q rows are complete in the slab (their pieces are older than what hand-over 7 waited
+        // for): into registers first, then the slab turns the accumulators' [d][query] lanes into rows -- 8-byte chunks in, 16-byte
+        // chunks out, chunk index XOR-swizzled by (row >> 1) & 3 inside groups of four so that the 16 rows a store instruction's lane
+        // group covers do not meet on two banks
+        read_q();
+        {
+            const float inv = __builtin_amdgcn_rcpf(half_sum(l_run));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            char* slab = smem + A_RING + wave * A_KTILE;
+            const int wrow = l31 * A_ROWB + 8 * half, wsw = (l31 >> 1) & 3;
+#pragma unroll
+            for (int db = 0; db < A_NDB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const h16x2 v0 = __builtin_convertvector((f32x2){o[db][4 * g] * inv, o[db][4 * g + 1] * inv}, h16x2);
+                    const h16x2 v1 = __builtin_convertvector((f32x2){o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv}, h16x2);
+                    const u32x2 w = {__builtin_bit_cast(unsigned, v0), __builtin_bit_cast(unsigned, v1)};
+                    *reinterpret_cast<u32x2*>(slab + wrow + ((4 * db + (g ^ wsw)) << 4)) = w;
+                }
+            const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)og + cur.oo), 0, 31 * rbo + A_ROWB, 0x00020000);
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int f = 64 * (i % 5) + ln;
+                const int r5 = (f * 3277) >> 16, pos = f - r5 * 20, r = r5 + 16 * (i / 5);
+                const int ch = (pos & ~3) | ((pos & 3) ^ ((r >> 1) & 3));
+                const u32x4 d = *reinterpret_cast<const u32x4*>(slab + r * A_ROWB + (ch << 4));
+                __builtin_amdgcn_raw_buffer_store_b128(d, rO, r * rbo + (pos << 4), 0, 0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slab has been read: the next hand-over's Q pieces may land
+        }
+        if (!has_next) break;
+        cur = nxt;
+        ++it;
+    }
+    wait_vm<0>();
+}
+
 // workgroups the launch uses: one per CU, a multiple of 16 (two directions x eight XCDs), no more than the units there are
 int tail160_grid(int n_pairs, int B, int H) {
     int g = cu_count() & ~15;
@@ -585,6 +834,31 @@ int g_tail160_exp = 0;
 #endif
 
 bool pair_score160_applies(int N, int D, int dtype) { return N == A_N && D == A_D && dtype == DSIM_H16; }
+
+// the U-Net's 256-token, d = 160 self-attention on the persistent core: 16-bit types, one K / V per query batch element, 16-byte rows
+bool sdpa160_applies(const AttnArgs& a) {
+    if (a.D != A_D || a.Nq != A_N || a.Nk != A_N || a.Bkv != a.B || a.B < 1 || a.H < 1) return false;
+    if (a.ldq % 8 || a.ldk % 8 || a.ldo % 8) return false;
+    if (((size_t)a.q | (size_t)a.k | (size_t)a.v | (size_t)a.out) & 15) return false;
+    // 32-bit buffer offsets inside one (batch element, head) view
+    return (long)(A_N - 1) * a.ldq * 2 + A_ROWB < (1l << 31) && (long)(A_N - 1) * a.ldk * 2 + A_ROWB < (1l << 31);
+}
+
+int launch_sdpa160(const AttnArgs& a, hipStream_t s) {
+    int g = cu_count() & ~63;
+    if (g < 64) g = 64;
+    if (g > 512) g = 512;
+    const long need = (((long)a.B * a.H + 63) / 64) * 64;
+    if (need < g) g = (int)need;
+    static DeviceOnce once;
+    auto kern = sdpa160_kernel;
+    CK_ONCE(once, kern, A_LDS);
+    const float c = (1.0f / sqrtf((float)A_D)) * 1.4426950408889634f;
+    hipLaunchKernelGGL(kern, dim3(g), dim3(512), A_LDS, s, (const h16*)a.q, (const h16*)a.k, (const h16*)a.v, (h16*)a.out, a.ldq, a.ldk,
+                       a.ldo, a.B, a.H, c);
+    DSIM_HIP_CHECK(hipGetLastError());
+    return DSIM_OK;
+}
 
 static size_t tail160_part_bytes(int n_pairs, int B, int H) { return (((size_t)n_pairs * 2 * B * H * 8 * 4 * sizeof(float)) + 255) & ~(size_t)255; }
 

@@ -34,6 +34,8 @@
 #define pair_score160_applies pair_score160_applies_f16
 #define pair_score160_scratch_bytes pair_score160_scratch_bytes_f16
 #define launch_pair_score160 launch_pair_score160_f16
+#define sdpa160_applies sdpa160_applies_f16
+#define launch_sdpa160 launch_sdpa160_f16
 #define ff_stream_bytes ff_stream_bytes_f16
 #define pack_ff_stream pack_ff_stream_f16
 #define launch_ff_fused launch_ff_fused_f16
@@ -175,13 +177,14 @@ extern int g_attn_dbg;          // ablation mask of attn_long_kernel
 extern int g_attn_short;        // 0 = short key sequences through attn_kernel
 extern int g_attn_fast_min;     // fewest keys that take the fixed-reference softmax of attn_kernel
 extern int g_tail160;           // 0 = the 256-token d = 160 score tail through pair_tail_kernel
+extern int g_sdpa160;           // 0 = the 256-token d = 160 self-attention through attn_kernel
 extern float* g_tail160_dbg;    // kbench: device buffer for the first unit's two attention outputs
 extern int g_tail160_exp;       // kbench: experiment mask of pair_tail160_kernel
 extern int g_ff_dbg;            // ablation mask of the fused feed-forward kernel (rowres.hip)
 extern int g_rl_dbg;            // ablation mask of the row-resident Linear kernel (rowres.hip)
 extern int g_ff_stagger;        // its wave de-phasing, in s_nop 7 units per wave index
 #else
-constexpr int g_gemm_skinny = 1, g_gemm_persistent = 1, g_force_bm = 0, g_gn_onepass = 1, g_ln_rows = 1, g_prep8 = 1, g_attn_q2 = 1, g_attn_short = 1, g_attn_fast_min = 1024, g_tail160 = 1;
+constexpr int g_gemm_skinny = 1, g_gemm_persistent = 1, g_force_bm = 0, g_gn_onepass = 1, g_ln_rows = 1, g_prep8 = 1, g_attn_q2 = 1, g_attn_short = 1, g_attn_fast_min = 1024, g_tail160 = 1, g_sdpa160 = 1;
 #endif
 int gemm_fill_extents(GemmArgs& g, size_t es);                       // operand byte extents for the buffer descriptors
 bool gemm_skinny_applies(const GemmArgs& a);                         // small-batch kernel (gemm_skinny.hip): same arithmetic, deep ring
@@ -296,6 +299,9 @@ bool pair_score160_applies(int N, int D, int dtype);
 size_t pair_score160_scratch_bytes(int n_pairs, int B, int H);
 int launch_pair_score160(const void* q, const void* k, const void* v, const int32_t* idx_a, const int32_t* idx_b, int n_pairs, int B,
                          int H, int mse, float* out, void* scratch, size_t scratch_bytes, hipStream_t s, int32_t* status);
+// the same core as a plain SDPA (256 queries = 256 keys, head dim 160, 16-bit types): the U-Net's 16 x 16-level self-attentions
+bool sdpa160_applies(const AttnArgs& a);
+int launch_sdpa160(const AttnArgs& a, hipStream_t s);
 
 // row-resident fused feed-forward of the 320-channel transformer blocks (h16) -- rowres.hip
 //   out = x + W2 (h * gelu(g)) + b2,  [h ; g] = W1 LN(x) + b1

@@ -109,3 +109,56 @@ def test_persistent_tail_reports_non_finite_features_per_pair(eng):
     s, st = eng.pair_score(q, k, v, ia, ib, H, "cosine", return_status=True)
     assert st.cpu().tolist() == [0, 1, 0, 1]
     assert torch.isfinite(s[[0, 2]]).all()
+
+
+# ---- the same core as the U-Net's own 256-token self-attention (sdpa160_kernel), through dsim_op_attention ------------------------
+def _attention_fused_rows(qkv, out_ld=None):
+    """qkv: [B][256][3 C] cuda tensor as the fused q|k|v projection writes it (q, k, v are column blocks of one row) -> [B][256][C]"""
+    from diffsim_amd import _lib, engine
+    L = _lib.lib()
+    Bn, Nn, C3 = qkv.shape
+    C = C3 // 3
+    out = torch.full((Bn, Nn, C), float("nan"), dtype=qkv.dtype, device=qkv.device)
+    es = qkv.element_size()
+    _lib.check(L.dsim_op_attention(qkv.data_ptr(), C3, qkv.data_ptr() + C * es, qkv.data_ptr() + 2 * C * es, C3, out.data_ptr(), C, Bn, Bn, H,
+                                   Nn, Nn, C // H, engine._TORCH2DSIM[qkv.dtype], engine._stream_ptr()), "op_attention")
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("nb", [3, 40])
+def test_persistent_self_attention_matches_float64_sdpa(eng, dtype, nb):
+    """nb = 3: fewer units than workgroups; nb = 40: 320 (batch element, head) units on 256 workgroups -- some walk two units (the
+    next unit's Q pieces under the current one, the output stores in flight under the next unit's first steps), most end after one."""
+    g = torch.Generator().manual_seed(21 + nb)
+    qkv = torch.randn(nb, N, 3 * H * D, generator=g)
+    qkv[..., : 2 * H * D] *= 1.3
+    qkv = qkv.to(dtype).cuda().contiguous()
+    got = _attention_fused_rows(qkv)
+    assert torch.isfinite(got.float()).all()
+    x = qkv.cpu().double().view(nb, N, 3, H, D)
+    want = F.scaled_dot_product_attention(x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2))
+    want = want.transpose(1, 2).reshape(nb, N, H * D)
+    # P is rounded to the 16-bit type before the PV products (a random error of ~2^-9 / 2^-12 of the dominant |p v| terms, maximum
+    # taken over up to 1.3e7 values) and the output once more (half a unit in its last place)
+    atol, rtol = (4e-3, 1.6e-2) if dtype == torch.bfloat16 else (5e-4, 2e-3)
+    excess = ((got.cpu().double() - want).abs() / (atol + rtol * want.abs())).max().item()
+    assert excess <= 1.0, excess
+    # repeat calls bit-identical; a batch element's rows do not depend on the batch it is computed in
+    assert torch.equal(got, _attention_fused_rows(qkv))
+    for b in (0, nb - 1):
+        assert torch.equal(got[b], _attention_fused_rows(qkv[b:b + 1].contiguous())[0])
+
+
+def test_persistent_self_attention_peaked_rows(eng):
+    """logits with ~25 log2 units of spread: the rescale branch"""
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(2, N, 3 * H * D, generator=g)
+    qkv[..., : H * D] *= 14.0
+    qkv = qkv.to(torch.bfloat16).cuda().contiguous()
+    got = _attention_fused_rows(qkv)
+    x = qkv.cpu().double().view(2, N, 3, H, D)
+    want = F.scaled_dot_product_attention(x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2))
+    want = want.transpose(1, 2).reshape(2, N, H * D)
+    assert torch.isfinite(got.float()).all()
+    assert (got.cpu().double() - want).abs().max().item() <= 4e-2          # near-one-hot rows: outputs up to ~4, bf16 steps of 2^-6

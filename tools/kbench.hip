@@ -213,6 +213,8 @@ static void bench_gemm(const char* name, int mode, int M, int N, int Cin, int H,
     HC(hipFree(A)); if (A1) HC(hipFree(A1)); HC(hipFree(Wt)); HC(hipFree(bias)); HC(hipFree(res)); HC(hipFree(out));
 }
 
+static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float r; memcpy(&r, &u, 4); return r; }
+
 static void bench_attn(const char* name, int B, int Bkv, int H, int Nq, int Nk, int D, int iters, Timer& t) {
     if (!want(name)) return;
     const int C = H * D;
@@ -244,6 +246,35 @@ static void bench_attn(const char* name, int B, int Bkv, int H, int Nq, int Nk, 
         }
         std::sort(q1.begin(), q1.end()); std::sort(q2.begin(), q2.end());
         printf("  tiled kernel %8.3f/%8.3f ms | short-key kernel %8.3f/%8.3f ms (min/median)\n", q1[0], q1[rounds / 2], q2[0], q2[rounds / 2]);
+    }
+    if (self && D == 160 && Nq == 256) {          // the tiled kernel against the persistent core (attn160.hip), and their outputs against each other
+        std::vector<float> q1, q2;
+        const size_t no = (size_t)B * Nq * C;
+        std::vector<unsigned short> h0(no), h1(no);
+        g_sdpa160 = 0;
+        HC(hipMemset(out, 0xff, no * 2));
+        st = launch_attention(a, DSIM_BF16, 0);
+        HC(hipMemcpy(h0.data(), out, no * 2, hipMemcpyDeviceToHost));
+        g_sdpa160 = 1;
+        HC(hipMemset(out, 0xff, no * 2));
+        st = launch_attention(a, DSIM_BF16, 0);
+        HC(hipMemcpy(h1.data(), out, no * 2, hipMemcpyDeviceToHost));
+        double md = 0, mx = 0; size_t nbad = 0, ndiff = 0;
+        for (size_t i = 0; i < no; ++i) {
+            const float x = bf2f(h0[i]), y = bf2f(h1[i]);
+            if (!(y - y == 0.0f)) ++nbad;
+            if (h0[i] != h1[i]) ++ndiff;
+            md = std::max(md, (double)fabsf(x - y)); mx = std::max(mx, (double)fabsf(x));
+        }
+        for (int r = 0; r < rounds; ++r) {
+            g_sdpa160 = 0;
+            q1.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
+            g_sdpa160 = 1;
+            q2.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
+        }
+        std::sort(q1.begin(), q1.end()); std::sort(q2.begin(), q2.end());
+        printf("  tiled kernel %8.4f/%8.4f ms | persistent core %8.4f/%8.4f ms (min/median)   outputs: max |diff| %.3g of max %.3g, %zu of %zu differ, %zu non-finite\n",
+               q1[0], q1[rounds / 2], q2[0], q2[rounds / 2], md, mx, ndiff, no, nbad);
     }
     if (Nk >= 256 && Nk < 2048) {                 // exact running maximum against the fixed-reference softmax at mid-length key sequences
         std::vector<float> q1, q2;

@@ -70,7 +70,7 @@ def rocprof_name(fam: str) -> str:
         if kind == "p160":
             return "sdpa160_kernel"
         if kind == "short":
-            return f"attn_short_kernel<{d}>"
+            return f"attn_short_kernel<{d}, true>"          # (the 77-key prompt context: the K80 instantiation)
         if kind == "long":
             return f"attn_long_kernel<{d}, 0>"
         if kind in ("q2", "q2fast"):

@@ -123,6 +123,57 @@ __device__ __forceinline__ void load_q(QFrags<T, D>& qf, const T* qrow /*row bas
     }
 }
 
+// One wave's 32 output rows from its O^T accumulators.  A lane owns one query row and, per 32-wide block db, the 8-byte chunks
+// d = 32 db + 8 g + 4 half + (0..3): stored as they lie, a wave instruction writes 16 bytes into each of 32 rows -- 32 cache-line
+// operations for 512 bytes, and the texture path, not HBM, sets the time (a 77-key cross-attention spent 0.29 of its 0.49 ms on
+// them: profiles/r06_experiments.txt item 4).  The two halves of the wave therefore exchange every other chunk first (one
+// v_permlane32_swap per register; both lanes of a pair belong to the same row), each lane stores 16 contiguous bytes, and the
+// row gets 32 bytes per instruction from half as many instructions.  val(db, r) = the value to store for accumulator register r.
+template <int D, typename F>
+__device__ __forceinline__ void store_o_rows(h16* orow, int half, bool wide, F&& val) {
+    constexpr int NDB = (D + 31) / 32;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    if (wide) {
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                const int d0 = db * 32 + 16 * gp;
+                if (d0 < D) {
+                    unsigned a[2], b[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const h16x2 va = __builtin_convertvector((f32x2){val(db, 8 * gp + 2 * e), val(db, 8 * gp + 2 * e + 1)}, h16x2);
+                        const h16x2 vb = __builtin_convertvector((f32x2){val(db, 8 * gp + 4 + 2 * e), val(db, 8 * gp + 4 + 2 * e + 1)}, h16x2);
+                        a[e] = __builtin_bit_cast(unsigned, va);
+                        b[e] = __builtin_bit_cast(unsigned, vb);
+                    }
+                    // lower lanes keep chunk 2 gp and receive the partner's; upper lanes keep chunk 2 gp + 1 and receive the partner's
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+                    const u32x4 w = {r0[0], r1[0], r0[1], r1[1]};
+                    const int d = d0 + 8 * half;
+                    if (d < D) *reinterpret_cast<u32x4*>(orow + d) = w;
+                }
+            }
+    } else {
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = db * 32 + 8 * g + 4 * half;
+                if (d < D) {
+                    h16x4 v4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v4[j] = (h16)val(db, 4 * g + j);
+                    *reinterpret_cast<h16x4*>(orow + d) = v4;
+                }
+            }
+    }
+}
+// 16-byte row segments need 16-byte aligned rows
+__device__ __forceinline__ bool wide_rows(const AttnArgs& p) { return p.ldo % 8 == 0 && ((size_t)p.out & 15) == 0; }
+
 // Staging of one KT-row tile of K and V, split in a load half and a store half so the global loads can be
 // issued a whole tile ahead of the LDS writes.  Only the D real columns move per tile: the zero padding up
 // to DPL columns (and, with ONES, the 1.0 in column D of V) is written ONCE per attend() by tile_init.
@@ -865,18 +916,7 @@ __global__ __launch_bounds__(256, 2) void attn_long_kernel(const AttnArgs p, con
     for (int qb = 0; qb < 2; ++qb) {
         if (q[qb] >= p.Nq) continue;
         T* orow = (T*)p.out + ((size_t)b * p.Nq + q[qb]) * p.ldo + h * D;
-#pragma unroll
-        for (int db = 0; db < C::NDB; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = db * 32 + 8 * g + 4 * half;
-                if (d < D) {
-                    h16x4 v4;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v4[j] = (h16)oa[qb].b[db][4 * g + j];
-                    *reinterpret_cast<h16x4*>(orow + d) = v4;
-                }
-            }
+        store_o_rows<D>(orow, half, wide_rows(p), [&](int db, int r) { return oa[qb].b[db][r]; });
     }
 }
 
@@ -915,18 +955,7 @@ __global__ __launch_bounds__(256, 2) void attn_q2_kernel(const AttnArgs p, const
     for (int qb = 0; qb < 2; ++qb) {
         if (q[qb] >= p.Nq) continue;
         T* orow = (T*)p.out + ((size_t)b * p.Nq + q[qb]) * p.ldo + h * D;
-#pragma unroll
-        for (int db = 0; db < C::NDB; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = db * 32 + 8 * g + 4 * half;
-                if (d < D) {
-                    h16x4 v4;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v4[j] = (h16)oa[qb].b[db][4 * g + j];
-                    *reinterpret_cast<h16x4*>(orow + d) = v4;
-                }
-            }
+        store_o_rows<D>(orow, half, wide_rows(p), [&](int db, int r) { return oa[qb].b[db][r]; });
     }
 }
 
@@ -959,25 +988,22 @@ __global__ __launch_bounds__(256, (ACfg<T, D>::WPS)) void attn_kernel(const Attn
     auto& o = oa.b;
     if (q < p.Nq) {
         T* orow = (T*)p.out + ((size_t)b * p.Nq + q) * p.ldo + h * D;
+        if constexpr (sizeof(T) == 2) {
+            store_o_rows<D>((h16*)orow, half, wide_rows(p), [&](int db, int r) { return o[db][r]; });
+        } else {
 #pragma unroll
-        for (int db = 0; db < C::NDB; ++db)
+            for (int db = 0; db < C::NDB; ++db)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = db * 32 + 8 * g + 4 * half;
-                if (d < D) {
-                    if constexpr (sizeof(T) == 2) {
-                        h16x4 v4;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v4[j] = (h16)o[db][4 * g + j];
-                        *reinterpret_cast<h16x4*>(orow + d) = v4;
-                    } else {
+                for (int g = 0; g < 4; ++g) {
+                    const int d = db * 32 + 8 * g + 4 * half;
+                    if (d < D) {
                         f32x4 v4;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v4[j] = o[db][4 * g + j];
                         *reinterpret_cast<f32x4*>(orow + d) = v4;
                     }
                 }
-            }
+        }
     }
 }
 
@@ -990,8 +1016,10 @@ __global__ __launch_bounds__(256, (ACfg<T, D>::WPS)) void attn_kernel(const Attn
 // it is: a stream of Q in and O out.  h16; K / V images in attn_kernel's padded row-major layouts (ones column of V included).
 // The heads of a token share cache lines in Q and O (80 bytes per head at d = 40): the XCD-aware block order that keeps the
 // heads of a batch element on one XCD matters more than anything inside the loop (0.62 -> 0.46 ms at d = 40).
+#ifdef DSIM_DEVTOOLS
+// (kbench only: round 5's form of the kernel below, for interleaved A/B -- g_attn_short = 2)
 template <int D>
-__global__ __launch_bounds__(256, (D <= 80 ? 4 : 2)) void attn_short_kernel(const AttnArgs p, const float scale_log2, const int qit) {
+__global__ __launch_bounds__(256, (D <= 80 ? 4 : 2)) void attn_short_v1_kernel(const AttnArgs p, const float scale_log2, const int qit) {
     typedef h16 T;
     typedef ACfg<T, D> C;
     constexpr int KR = 96;                                   // key rows held (three 32-row MFMA blocks)
@@ -1128,6 +1156,178 @@ __global__ __launch_bounds__(256, (D <= 80 ? 4 : 2)) void attn_short_kernel(cons
     }
 }
 
+#endif
+
+// Round 6 (profiles/r06_experiments.txt item 4): the loop was bound by its vector instructions (493 per 32-query block against 21
+// MFMAs; vector pipe 0.46 busy, matrix pipe 0.14), so
+//  - Q is NOT pre-scaled (24 multiplies + conversions per block): the softmax computes exp2(fma(s, c, -m c)) as packed v_pk_fma_f32;
+//  - K80 (64 < Nk <= 80: the 77-key prompt context): the ragged third key block takes its -inf mask as eight loop-invariant
+//    addends instead of 48 compares + selects per block (whose 48 lane masks hipcc kept in VGPR lanes: a v_readlane each), and
+//    its dead upper half (keys 80-95) is never exponentiated or multiplied;
+//  - a workgroup walks query blocks ACROSS the batch elements that share its K / V (b = bkv, bkv + Bkv, ...: the CFG halves of every
+//    image read the same prompt), so the 256-query level of the U-Net (d = 160: two blocks per batch element) amortises its staging
+//    over eight blocks like the others; block order [bkv][chunk][head]: the heads of a row stay neighbours on one XCD.
+template <int D, bool K80>
+__global__ __launch_bounds__(256, (D <= 80 ? 4 : 2)) void attn_short_kernel(const AttnArgs p, const float scale_log2, const int qit_) {
+#ifdef DSIM_DEVTOOLS
+    const int qit = qit_ & 255, abl = qit_ >> 8;        // kbench ablations: 1 = no output stores, 2 = no Q prefetch loads (timing only)
+#else
+    const int qit = qit_;
+    constexpr int abl = 0;
+#endif
+    typedef h16 T;
+    typedef ACfg<T, D> C;
+    constexpr int KR = 96;                                   // key rows held (three 32-row MFMA blocks)
+    constexpr int CPRD = D / C::VEC;                         // real 16-byte chunks per row
+    constexpr int VOFF = KR * C::RS;                         // V image behind the K image
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int nqb = (p.Nq + 127) / 128;                      // query blocks per batch element
+    const int nbmax = (p.B + p.Bkv - 1) / p.Bkv;             // batch elements per K / V
+    const int nch = (nbmax * nqb + qit - 1) / qit;           // chunks of qit blocks per (K / V, head)
+    int bid = blockIdx.x;
+    if (p.xcd_remap) {          // every XCD a contiguous run of (K / V, chunk, head) items -- the heads of a row share cache lines
+        const int nwg = gridDim.x, xcd = bid & 7, qq = nwg >> 3, r = nwg & 7, slot = bid >> 3;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + slot;
+    }
+    const int h = bid % p.H, t0 = bid / p.H, ch = t0 % nch, bkv = t0 / nch;
+    const int nbg = (p.B - bkv + p.Bkv - 1) / p.Bkv;         // batch elements that read this K / V
+    if (ch * qit >= nbg * nqb) return;
+    const size_t kvoff = (size_t)bkv * p.Nk * p.ldk + h * D;
+    const T* kb = (const T*)p.k + kvoff;
+    const T* vb = (const T*)p.v + kvoff;
+    // ---- stage K and V once: zero image (padding columns, rows >= Nk), then the real chunks and V's ones column ---------
+    {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int o = tid * 16; o < KR * (C::RS + C::RSV); o += 256 * 16) *reinterpret_cast<u32x4*>(smem + o) = z;
+        __syncthreads();
+        for (int idx = tid; idx < p.Nk * CPRD; idx += 256) {
+            const int r = idx / CPRD, c = idx - r * CPRD;
+            const u32x4 kk = *reinterpret_cast<const u32x4*>(kb + (size_t)r * p.ldk + c * C::VEC);
+            const u32x4 vv = *reinterpret_cast<const u32x4*>(vb + (size_t)r * p.ldk + c * C::VEC);
+            *reinterpret_cast<u32x4*>(smem + r * C::RS + c * 16) = kk;
+            *reinterpret_cast<u32x4*>(smem + VOFF + r * C::RSV + c * 16) = vv;
+        }
+        if constexpr (C::ONES)
+            for (int r = tid; r < p.Nk; r += 256) *reinterpret_cast<u32x4*>(smem + VOFF + r * C::RSV + CPRD * 16) = one_chunk<T>();
+        __syncthreads();
+    }
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const char* const kfr = smem + l31 * C::RS + half * 16;
+    const char* const vfr = smem + VOFF + (4 * (g4 >> 1) + (i16 >> 2)) * C::RSV + (16 * (g4 & 1) + 4 * (i16 & 3)) * 2;
+    // unscaled Q fragments of a block's 32 rows of this wave (rows past the end: the last row, never stored)
+    auto load_q_raw = [&](QFrags<T, D>& f, int b, int q) {
+        const int qq = q < p.Nq ? q : p.Nq - 1;
+        const T* qrow = (const T*)p.q + ((size_t)b * p.Nq + qq) * p.ldq + h * D;
+#pragma unroll
+        for (int ks = 0; ks < C::NKS; ++ks) {
+            const int d0 = 16 * ks + 8 * half;
+            if (d0 < D) f.f[ks] = *reinterpret_cast<const h16x8*>(qrow + d0);
+            else zero_frag(f.f[ks]);
+        }
+    };
+    // K80: the third key block's mask as eight loop-invariant addends (key = 64 + (r & 3) + 8 (r >> 2) + 4 half; r >= 8 is dead)
+    float bias[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bias[r] = (64 + (r & 3) + 8 * (r >> 2) + 4 * half >= p.Nk) ? -INFINITY : 0.f;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 c2 = {scale_log2, scale_log2};
+    const bool wide = wide_rows(p);
+
+    int bi = (ch * qit) / nqb, qblk = ch * qit - bi * nqb;
+    QFrags<T, D> qf;
+    load_q_raw(qf, bi * p.Bkv + bkv, qblk * 128 + wave * 32 + l31);
+    for (int it = 0; it < qit && bi < nbg; ++it) {
+        const int b = bi * p.Bkv + bkv;
+        const int q = qblk * 128 + wave * 32 + l31;
+        if (++qblk == nqb) { qblk = 0; ++bi; }
+        // the next block's Q rows fly while this block computes
+        QFrags<T, D> qn;
+        if (!(abl & 2)) load_q_raw(qn, (bi < nbg ? bi : nbg - 1) * p.Bkv + bkv, qblk * 128 + wave * 32 + l31);
+        else qn = qf;
+        if (q - l31 < p.Nq) {                               // wave-uniform: some of this wave's rows exist
+            f32x16 s[3];
+#pragma unroll
+            for (int kbk = 0; kbk < 3; ++kbk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kbk][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < C::NKS; ++ks) {
+                    h16x8 kf;
+                    lload_frag(kf, kfr + kbk * 32 * C::RS + ks * 32);
+                    mma(kf, qf.f[ks], s[kbk]);
+                }
+            }
+            // exact row maximum over the (<= 96) keys: lane-local + one exchange between the halves
+            float m = -INFINITY;
+#pragma unroll
+            for (int kbk = 0; kbk < 3; ++kbk)
+#pragma unroll
+                for (int r = 0; r < ((K80 && kbk == 2) ? 8 : 16); ++r) {
+                    if constexpr (!K80) {
+                        const int kv = kbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (kv >= p.Nk) s[kbk][r] = -INFINITY;
+                    } else if (kbk == 2) {
+                        s[kbk][r] += bias[r];
+                    }
+                    m = fmaxf(m, s[kbk][r]);
+                }
+            m = max_halves(m);
+            const float mc = -m * scale_log2;
+            const f32x2 m2 = {mc, mc};
+            float psum = 0.f;
+#pragma unroll
+            for (int kbk = 0; kbk < 3; ++kbk)
+#pragma unroll
+                for (int r = 0; r < ((K80 && kbk == 2) ? 8 : 16); r += 2) {
+                    const f32x2 e = __builtin_elementwise_fma((f32x2){s[kbk][r], s[kbk][r + 1]}, c2, m2);
+                    s[kbk][r] = __builtin_amdgcn_exp2f(e[0]);
+                    s[kbk][r + 1] = __builtin_amdgcn_exp2f(e[1]);
+                    if constexpr (!C::ONES) psum += s[kbk][r] + s[kbk][r + 1];
+                }
+            f32x16 o[C::NDB];
+#pragma unroll
+            for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+#pragma unroll
+            for (int kbk = 0; kbk < 3; ++kbk)
+#pragma unroll
+                for (int s2 = 0; s2 < ((K80 && kbk == 2) ? 1 : 2); ++s2) {
+                    h16x8 pf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[e] = (h16)s[kbk][8 * s2 + e];
+#pragma unroll
+                    for (int db = 0; db < C::NDB; ++db) {
+                        const char* pa = vfr + (kbk * 32 + 16 * s2) * C::RSV + db * 64;
+                        const h16x4 lo = h16_ds_read_tr16_b64((pa));
+                        const h16x4 hi = h16_ds_read_tr16_b64((pa + 8 * C::RSV));
+                        h16x8 vf;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = hi[e]; }
+                        o[db] = H16_MFMA_32x32x16(vf, pf, o[db], 0, 0, 0);
+                    }
+                }
+            float l_tot;
+            if constexpr (C::ONES) {
+                constexpr int RB = D / 32, RR = D % 32;
+                constexpr int RH = (RR >> 2) & 1, REG = (RR & 3) + 4 * (RR >> 3);
+                const float mine = o[RB][REG];
+                const float other = __shfl_xor(mine, 32);
+                l_tot = (half == RH) ? mine : other;
+            } else {
+                l_tot = psum + __shfl_xor(psum, 32);
+            }
+            const float inv = 1.0f / l_tot;
+            if (q < p.Nq && !(abl & 1)) {
+                T* orow = (T*)p.out + ((size_t)b * p.Nq + q) * p.ldo + h * D;
+                store_o_rows<D>(orow, half, wide, [&](int db, int r) { return o[db][r] * inv; });
+            }
+        }
+        qf = qn;
+    }
+}
+
 // ---- fused score tail ----------------------------------------------------------------------
 // grid (ceil(N/128), B*H, n_pairs*2); partial layout [pair][dir][bh][qtile][4] f32
 // 16-bit modes (round 5): both SDPA outputs are rounded to the compute dtype before the products -- torch's SDPA returns
@@ -1252,6 +1452,12 @@ __global__ void pair_finish_kernel(const float* __restrict__ part, int n_pairs, 
 
 inline float scale_log2_of(int D) { return (1.0f / sqrtf((float)D)) * 1.4426950408889634f; }
 
+#ifdef DSIM_DEVTOOLS
+#define DSIM_SHORT_QIT(q) ((q) | (g_attn_dbg << 8))
+#else
+#define DSIM_SHORT_QIT(q) (q)
+#endif
+
 template <typename T, int D>
 int launch_attn_d(const AttnArgs& a, hipStream_t s) {
     typedef ACfg<T, D> C;
@@ -1260,21 +1466,45 @@ int launch_attn_d(const AttnArgs& a, hipStream_t s) {
     // 4096 keys x d = 40, 10 % at 1024 keys x d = 80, 14 % at 1024 keys x d = 64 (SDXL); short ones (cross-attention's 77 keys,
     // the 16 x 16 level: 0.179 -> 0.195 ms at 256 keys x d = 160) keep the exact running maximum -- there the end-of-block check
     // costs more than the skipped maxima save
-    if constexpr (sizeof(T) == 2 && (D == 40 || D == 64 || D == 80)) {
+    if constexpr (sizeof(T) == 2 && (D == 40 || D == 64 || D == 80 || D == 160)) {
         // the prompt context of the cross-attentions (77 keys): keys resident in LDS, several query blocks per workgroup
         // (interleaved A/B at 64 pairs: d = 40 0.502 -> 0.464 ms, d = 80 0.257 -> 0.227 ms; d = 160 at 256 queries: no gain, not used)
         // (d = 64, SDXL, 32 pairs of rows: 1024 queries 0.055 -> 0.051 ms, 4096 queries 0.118 -> 0.123: the tiled kernel keeps those)
         if (a.Nk <= 96 && g_attn_short && (D != 64 || a.Nq <= 1024)) {
             constexpr int LDSS = 96 * (C::RS + C::RSV);
-            static DeviceOnce onces;
-            auto kern = attn_short_kernel<D>;
-            CK_ONCE(onces, kern, LDSS);
-            // query blocks per workgroup: as many as keep >= 8 workgroups per CU in the grid (at most 8)
-            const int nqb = (a.Nq + 127) / 128;
+#ifdef DSIM_DEVTOOLS
+            if (g_attn_short == 2) {
+                static DeviceOnce onces;
+                auto kern = attn_short_v1_kernel<D>;
+                CK_ONCE(onces, kern, LDSS);
+                const int nqb = (a.Nq + 127) / 128;
+                int qit = 8;
+                while (qit > 1 && (long)((nqb + qit - 1) / qit) * a.H * a.B < 8L * cu_count()) qit >>= 1;
+                hipLaunchKernelGGL(kern, dim3(((nqb + qit - 1) / qit) * a.H * a.B), dim3(256), LDSS, s, a, scale_log2_of(D), qit);
+                DSIM_HIP_CHECK(hipGetLastError());
+                return DSIM_OK;
+            }
+#endif
+            // query blocks per workgroup: as many as keep >= 8 workgroups per CU in the grid (at most 8); the 256-register d = 160
+            // instantiation (two workgroups per CU) is content with one full round.  A workgroup's blocks continue across the batch
+            // elements that share its K / V.
+            const int nqb = (a.Nq + 127) / 128, nvb = ((a.B + a.Bkv - 1) / a.Bkv) * nqb;
+            const long want = (D > 80 ? 2L : 8L) * cu_count();
             int qit = 8;
-            while (qit > 1 && (long)((nqb + qit - 1) / qit) * a.H * a.B < 8L * cu_count()) qit >>= 1;
-            const int nqc = (nqb + qit - 1) / qit;
-            hipLaunchKernelGGL(kern, dim3(nqc * a.H * a.B), dim3(256), LDSS, s, a, scale_log2_of(D), qit);
+            while (qit > 1 && (long)((nvb + qit - 1) / qit) * a.H * a.Bkv < want) qit >>= 1;
+            const int nch = (nvb + qit - 1) / qit;
+            const dim3 g(nch * a.H * a.Bkv);
+            if (a.Nk > 64 && a.Nk <= 80) {
+                static DeviceOnce onces;
+                auto kern = attn_short_kernel<D, true>;
+                CK_ONCE(onces, kern, LDSS);
+                hipLaunchKernelGGL(kern, g, dim3(256), LDSS, s, a, scale_log2_of(D), DSIM_SHORT_QIT(qit));
+            } else {
+                static DeviceOnce onces;
+                auto kern = attn_short_kernel<D, false>;
+                CK_ONCE(onces, kern, LDSS);
+                hipLaunchKernelGGL(kern, g, dim3(256), LDSS, s, a, scale_log2_of(D), DSIM_SHORT_QIT(qit));
+            }
             DSIM_HIP_CHECK(hipGetLastError());
             return DSIM_OK;
         }
@@ -1393,7 +1623,7 @@ int g_sdpa160 = 1;
 const char* attention_kernel_kind(const AttnArgs& a, int dtype) {
     if (dtype == DSIM_F32) return "";
     if (g_sdpa160 && sdpa160_applies(a)) return "_p160";
-    if ((a.D == 40 || a.D == 80 || (a.D == 64 && a.Nq <= 1024)) && a.Nk <= 96) return "_short";
+    if ((a.D == 40 || a.D == 80 || a.D == 160 || (a.D == 64 && a.Nq <= 1024)) && a.Nk <= 96) return "_short";
     if (a.D == 40 && a.Nk >= 2048 && a.Nk % KT == 0) return "_long";
     if (a.D == 64 && a.Nk > 96 && a.Nq >= 256) return a.Nk >= g_attn_fast_min ? "_q2fast" : "_q2";
     if (a.Nk >= g_attn_fast_min) return "_fast";

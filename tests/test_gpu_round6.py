@@ -162,3 +162,35 @@ def test_persistent_self_attention_peaked_rows(eng):
     want = want.transpose(1, 2).reshape(2, N, H * D)
     assert torch.isfinite(got.float()).all()
     assert (got.cpu().double() - want).abs().max().item() <= 4e-2          # near-one-hot rows: outputs up to ~4, bf16 steps of 2^-6
+
+
+# ---- the short-key cross-attention kernel after its round-6 rework (unscaled Q, mask addends, blocks walking across the batch
+# elements that share a K / V): /root/reference/diffsim/hacked_attn.py:74-81 with the 77-key prompt context ------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Bn,Bkv,Hn,Nq,Nk,Dn", [
+    (12, 2, 8, 256, 77, 160),       # the 16 x 16 level: two blocks per batch element, a workgroup walks across batch elements
+    (5, 2, 8, 200, 77, 160),        # batch not a multiple of the K / V count, ragged last query block
+    (7, 3, 4, 300, 65, 40),         # the ragged third key block at its shortest ...
+    (4, 2, 4, 130, 80, 80),         # ... and at its longest (the K80 instantiation's bounds)
+    (3, 1, 2, 128, 64, 40), (3, 3, 2, 160, 81, 80), (6, 2, 5, 1024, 77, 64),
+    (40, 2, 8, 1024, 77, 80)])      # more chunks than one round of workgroups
+def test_short_key_attention_walks_batches(eng, dtype, Bn, Bkv, Hn, Nq, Nk, Dn):
+    g = torch.Generator().manual_seed(Bn * 1000 + Nq + Nk + Dn)
+    q = (torch.randn(Bn, Nq, Hn * Dn, generator=g) * 1.3).to(dtype)
+    k = (torch.randn(Bkv, Nk, Hn * Dn, generator=g) * 1.3).to(dtype)
+    v = torch.randn(Bkv, Nk, Hn * Dn, generator=g).to(dtype)
+    idx = torch.arange(Bn) % Bkv
+    want = F.scaled_dot_product_attention(q.double().view(Bn, Nq, Hn, Dn).transpose(1, 2),
+                                          k.double()[idx].view(Bn, Nk, Hn, Dn).transpose(1, 2),
+                                          v.double()[idx].view(Bn, Nk, Hn, Dn).transpose(1, 2)).transpose(1, 2).reshape(Bn, Nq, Hn * Dn)
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    got = eng.op_attention(qd, kd, vd, Hn)
+    assert torch.isfinite(got.float()).all()
+    atol, rtol = (4e-3, 1.6e-2) if dtype == torch.bfloat16 else (5e-4, 2e-3)
+    excess = ((got.cpu().double() - want).abs() / (atol + rtol * want.abs())).max().item()
+    assert excess <= 1.0, excess
+    assert torch.equal(got, eng.op_attention(qd, kd, vd, Hn))
+    # a batch element's rows do not depend on the batch: element b alone, with its own K / V
+    b = Bn - 1
+    alone = eng.op_attention(qd[b:b + 1].contiguous(), kd[b % Bkv:b % Bkv + 1].contiguous(), vd[b % Bkv:b % Bkv + 1].contiguous(), Hn)
+    assert torch.equal(got[b], alone[0])

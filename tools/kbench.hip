@@ -236,16 +236,45 @@ static void bench_attn(const char* name, int B, int Bkv, int H, int Nq, int Nk, 
         a.xcd_remap = 1;
         m1.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
     }
-    if (Nk <= 96) {                               // keys resident in LDS (attn_short_kernel) against the tiled kernel
-        std::vector<float> q1, q2;
+    if (Nk <= 96) {                               // keys resident in LDS (attn_short_kernel; round 5's form of it) against the tiled kernel
+        std::vector<float> q1, q2, q3;
+        const size_t no = (size_t)B * Nq * C;
+        std::vector<unsigned short> h0(no), h1(no);
+        g_attn_short = 0;
+        HC(hipMemset(out, 0xff, no * 2));
+        st = launch_attention(a, DSIM_BF16, 0);
+        HC(hipMemcpy(h0.data(), out, no * 2, hipMemcpyDeviceToHost));
+        g_attn_short = 1;
+        HC(hipMemset(out, 0xff, no * 2));
+        st = launch_attention(a, DSIM_BF16, 0);
+        HC(hipMemcpy(h1.data(), out, no * 2, hipMemcpyDeviceToHost));
+        double md = 0, mx = 0; size_t nbad = 0;
+        for (size_t i = 0; i < no; ++i) {
+            const float x = bf2f(h0[i]), y = bf2f(h1[i]);
+            if (!(y - y == 0.0f)) ++nbad;
+            md = std::max(md, (double)fabsf(x - y)); mx = std::max(mx, (double)fabsf(x));
+        }
         for (int r = 0; r < rounds; ++r) {
             g_attn_short = 0;
             q1.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
+            g_attn_short = 2;
+            q3.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
             g_attn_short = 1;
             q2.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
         }
-        std::sort(q1.begin(), q1.end()); std::sort(q2.begin(), q2.end());
-        printf("  tiled kernel %8.3f/%8.3f ms | short-key kernel %8.3f/%8.3f ms (min/median)\n", q1[0], q1[rounds / 2], q2[0], q2[rounds / 2]);
+        if (getenv("KB_SHORTABL")) {              // ablations of the short-key kernel: 1 no output stores, 2 no Q prefetch, 3 neither
+            for (int m = 1; m <= 3; ++m) {
+                g_attn_dbg = m; g_attn_short = 1;
+                std::vector<float> qa;
+                for (int r = 0; r < rounds; ++r) qa.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
+                std::sort(qa.begin(), qa.end());
+                printf("  short-key kernel ablation %d: %8.3f ms\n", m, qa[rounds / 2]);
+            }
+            g_attn_dbg = 0;
+        }
+        std::sort(q1.begin(), q1.end()); std::sort(q2.begin(), q2.end()); std::sort(q3.begin(), q3.end());
+        printf("  tiled kernel %8.3f/%8.3f ms | short-key kernel, round 5 %8.3f/%8.3f ms | short-key kernel %8.3f/%8.3f ms (min/median)   vs tiled: max |diff| %.3g of max %.3g, %zu non-finite\n",
+               q1[0], q1[rounds / 2], q3[0], q3[rounds / 2], q2[0], q2[rounds / 2], md, mx, nbad);
     }
     if (self && D == 160 && Nq == 256) {          // the tiled kernel against the persistent core (attn160.hip), and their outputs against each other
         std::vector<float> q1, q2;

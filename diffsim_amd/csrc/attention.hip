@@ -1321,6 +1321,23 @@ __global__ __launch_bounds__(256, (D <= 80 ? 4 : 2)) void attn_short_kernel(cons
             const float inv = 1.0f / l_tot;
             if (q < p.Nq && !(abl & 1)) {
                 T* orow = (T*)p.out + ((size_t)b * p.Nq + q) * p.ldo + h * D;
+#ifdef DSIM_DEVTOOLS
+                if (abl & 4) {      // kbench: the same bytes as fully coalesced 1 KB wave stores at wrong addresses (timing only)
+                    char* base = (char*)p.out + (((size_t)b * p.Nq + (q - l31)) * p.ldo) * 2 + (size_t)h * 32 * D * 2;
+                    int i = 0;
+#pragma unroll
+                    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+                        for (int gp = 0; gp < 2; ++gp)
+                            if (db * 32 + 16 * gp < D) {
+                                u32x4 w;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(o[db][8 * gp + e] * inv);
+                                if (i * 1024 + lane * 16 < 32 * D * 2) *reinterpret_cast<u32x4*>(base + i * 1024 + lane * 16) = w;
+                                ++i;
+                            }
+                } else
+#endif
                 store_o_rows<D>(orow, half, wide, [&](int db, int r) { return o[db][r] * inv; });
             }
         }

@@ -262,8 +262,8 @@ static void bench_attn(const char* name, int B, int Bkv, int H, int Nq, int Nk, 
             g_attn_short = 1;
             q2.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
         }
-        if (getenv("KB_SHORTABL")) {              // ablations of the short-key kernel: 1 no output stores, 2 no Q prefetch, 3 neither
-            for (int m = 1; m <= 3; ++m) {
+        if (getenv("KB_SHORTABL")) {              // ablations of the short-key kernel: 1 no output stores, 2 no Q prefetch, 3 neither, 4 the output as coalesced 1 KB stores
+            for (int m = 1; m <= 4; ++m) {
                 g_attn_dbg = m; g_attn_short = 1;
                 std::vector<float> qa;
                 for (int r = 0; r < rounds; ++r) qa.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));

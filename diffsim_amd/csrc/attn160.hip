@@ -4,6 +4,8 @@
 //  * pair_tail160_kernel : the DiffSim score tail at the default tap -- /root/reference/diffsim/diffsim.py:177-197:
 //                          O_aa = SDPA(Qa, Ka, Va), O_ab = SDPA(Qa, Kb, Vb) (and the b <-> a mirror), cosine / mse over the
 //                          flattened (B, H, N, D) tensors -- for N = 256 tokens, head dim 160, 16-bit compute types.
+//  * sdpa160_kernel      : the same core as a plain SDPA -- the U-Net's own self-attentions of that level
+//                          (/root/reference/diffsim/hacked_attn.py:74-81); described where it is defined.
 //
 // Why a kernel of its own.  pair_tail_kernel<h16, 160> (attention.hip) gives a 128-query workgroup its own single-buffered
 // copy of every key tile: 50 % of its wave cycles wait for global loads or barriers and the matrix pipe is 0.2 busy.  The work

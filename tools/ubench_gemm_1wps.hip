@@ -129,6 +129,104 @@ __global__ __launch_bounds__(512, 2) void k_var0(const P p) {
     if (lane == 0) { p.clk[(blockIdx.x * 8 + wave) * 2] = t1 - t0; p.clk[(blockIdx.x * 8 + wave) * 2 + 1] = r1 - r0; }
 }
 
+// ---- VAR 3: TWO independent 4-wave workgroups per CU (round 6): 128 x 320 tiles as 2 x 2 waves of 64 x 160 -- the shipped wave tile --
+// with 64-byte LDS rows (one MFMA K step per stage, 2 stages = 56 KB per workgroup).  The two waves of a SIMD then belong to
+// different workgroups: they do not meet at one barrier, and (in a real kernel) one workgroup's epilogue runs under the other's K loop.
+// 16-row DMA pieces; the 16-byte chunk of row r sits at chunk c ^ f(r >> 2), f = (0, 2, 3, 1): conflict-free ds_read_b128 groups.
+__global__ __launch_bounds__(256, 2) void k_var3(const P p) {
+    constexpr int NW = 4, BM3 = 128, TM = 4, TN = 10, PS = 5, A_BYTES = BM3 * 64, STG = (BM3 + BN) * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane >> 2;
+    const unsigned lc = (unsigned)(lane & 3) ^ ((0x78u >> (2 * (lr >> 2))) & 3u);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)p.w_bytes, 0x00020000);
+    unsigned a_voff[2], b_voff[5];
+    auto setup = [&](int tile) {
+        const int m0 = (int)(((long)blockIdx.x * 16 + tile) % (p.arows / BM3)) * BM3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a_voff[i] = (unsigned)(m0 + (i * NW + wave) * 16 + lr) * (unsigned)p.K * 2u + lc * 16u;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) b_voff[i] = (unsigned)((i * NW + wave) * 16 + lr) * (unsigned)p.K * 2u + lc * 16u;
+    };
+    auto issue = [&](int t, int buf) {
+        char* sa = smem + buf * STG;
+        char* sb = sa + A_BYTES;
+        const int soff = t * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void*)(sa + (i * NW + wave) * 1024), 16, (int)a_voff[i], soff, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)(sb + (i * NW + wave) * 1024), 16, (int)b_voff[i], soff, 0, 0);
+    };
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = p.K / 32;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int foff = fr * 64 + ((fq ^ ((0x78 >> (2 * (fr >> 2))) & 3)) << 4);
+    bf16x8 xf[2][TM], wf[2][PS];
+    auto load_x = [&](int buf, int set) {
+        const char* sa = smem + buf * STG + wm * 64 * 64 + foff;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) xf[set][i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * 64);
+    };
+    auto load_w = [&](int buf, int piece, int set) {
+        const char* sb = smem + buf * STG + A_BYTES + (wn * 160 + piece * PS * 16) * 64 + foff;
+#pragma unroll
+        for (int j = 0; j < PS; ++j) wf[set][j] = *reinterpret_cast<const bf16x8*>(sb + j * 16 * 64);
+    };
+    auto mma_piece = [&](int piece, int xs) {
+#pragma unroll
+        for (int j = 0; j < PS; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                acc[i][piece * PS + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[piece][j], xf[xs][i], acc[i][piece * PS + j], 0, 0, 0);
+    };
+    long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    int b0 = 0;
+    setup(0);
+    issue(0, 0);
+    for (int tile = 0; tile < p.tiles; ++tile) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        load_x(b0, 0);
+        load_w(b0, 0, 0);
+        for (int t = 0; t < nk; t += 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {          // (two K steps per trip: the fragment sets alternate at compile time)
+                const int cur = b0 ^ u;
+                if (t + u + 1 < nk) issue(t + u + 1, cur ^ 1);
+                load_w(cur, 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_piece(0, u);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (t + u + 1 < nk) { load_x(cur ^ 1, u ^ 1); load_w(cur ^ 1, 0, 0); }
+                __builtin_amdgcn_sched_barrier(0);
+                mma_piece(1, u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // nk is even: the last step read buffer b0 ^ 1; the next tile's first stage goes to b0 and is read with set 0
+        if (tile + 1 < p.tiles) { setup(tile + 1); issue(0, b0); }
+    }
+    long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    atomicAdd(p.out + (blockIdx.x & 255), s);
+    if (lane == 0) { p.clk[(blockIdx.x * 4 + wave) * 2] = t1 - t0; p.clk[(blockIdx.x * 4 + wave) * 2 + 1] = r1 - r0; }
+}
+
 // ---- VAR 1 / VAR 2: one wave per SIMD, 128 x 160 per wave ---------------------------------------------------------------------
 // eight MFMAs that share one weight fragment: acc[i] += w x x[i]; accumulators in AGPRs ("a") or VGPRs ("v").  The leading s_nop
 // covers a VGPR written by the instruction in front of the statement (hipcc pads nothing for an asm statement).
@@ -368,7 +466,8 @@ int main(int argc, char** argv) {
     struct V { int var, ppg; const char* name; };
     const V vs[] = {{0, 0, "VAR0 8 waves 64x160 (shipped loop)"}, {1, 1, "VAR1 4 waves 128x160, 1 DMA piece / group"},
                     {1, 2, "VAR1 4 waves 128x160, 2 DMA pieces / group"}, {1, 3, "VAR1 4 waves 128x160, 3 DMA pieces / group"},
-                    {2, 0, "VAR2 4 waves 128x160, weights direct to registers"}};
+                    {2, 0, "VAR2 4 waves 128x160, weights direct to registers"},
+                    {3, 0, "VAR3 2 workgroups x 4 waves per CU, 128x320, 64-B rows"}};
     const int nv = sizeof(vs) / sizeof(vs[0]);
     std::vector<std::vector<float>> ms(nv);
     std::vector<std::vector<double>> ghz(nv);
@@ -377,7 +476,8 @@ int main(int argc, char** argv) {
         for (int v = 0; v < nv; ++v) {
             HC(hipMemset(p.out, 0, nb * 4));
             HC(hipEventRecord(a, 0));
-            if (vs[v].var == 0) hipLaunchKernelGGL(k_var0, dim3(nb), dim3(512), lds0, 0, p);
+            if (vs[v].var == 3) hipLaunchKernelGGL(k_var3, dim3(2 * nb), dim3(256), 2 * (128 + BN) * 64, 0, p);
+            else if (vs[v].var == 0) hipLaunchKernelGGL(k_var0, dim3(nb), dim3(512), lds0, 0, p);
             else if (vs[v].var == 1 && vs[v].ppg == 1) hipLaunchKernelGGL(k11, dim3(nb), dim3(256), lds0, 0, p);
             else if (vs[v].var == 1 && vs[v].ppg == 2) hipLaunchKernelGGL(k12, dim3(nb), dim3(256), lds0, 0, p);
             else if (vs[v].var == 1) hipLaunchKernelGGL(k13, dim3(nb), dim3(256), lds0, 0, p);
@@ -389,7 +489,8 @@ int main(int argc, char** argv) {
             std::vector<long long> hc(nb * 8 * 2);
             HC(hipMemcpy(hc.data(), p.clk, hc.size() * 8, hipMemcpyDeviceToHost));
             std::vector<double> g;
-            for (int i = 0; i < nb; ++i) for (int w = 0; w < nwv; ++w) g.push_back((double)hc[2 * (i * 8 + w)] / (double)hc[2 * (i * 8 + w) + 1] * 0.1);
+            if (vs[v].var == 3) { for (int i = 0; i < 2 * nb * 4; ++i) g.push_back((double)hc[2 * i] / (double)hc[2 * i + 1] * 0.1); }
+            else for (int i = 0; i < nb; ++i) for (int w = 0; w < nwv; ++w) g.push_back((double)hc[2 * (i * 8 + w)] / (double)hc[2 * (i * 8 + w) + 1] * 0.1);
             std::sort(g.begin(), g.end());
             std::vector<float> ho(nb);
             HC(hipMemcpy(ho.data(), p.out, nb * 4, hipMemcpyDeviceToHost));

@@ -480,6 +480,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
     bias_dma(0);
     stage(0, 0);
     bool first = true;
+    // INVARIANT of the counted wait at the top of a tile (s_waitcnt vmcnt(NST) below): behind the next tile's bias_dma + stage(0)
+    // EVERY wave issues EXACTLY NST = TM x NIT vector-memory operations per epilogue -- the output stores of its TM slabs x NIT
+    // pieces, unconditionally (edge pieces carry an out-of-range offset, they are not skipped); the residual LOADS of an epilogue are
+    // all waited for (their data is used) before its last store is issued; loads and stores retire in order (vmcnt on gfx9).  An
+    // epilogue form that makes a store conditional, or adds a vector-memory operation behind the stores, must change NST with it:
+    // the K loop would otherwise read LDS before the DMA landed.  (-DDSIM_DEVTOOLS builds: KB_GEXP bit 32768 waits vmcnt(0) instead,
+    // for A/B and for checking a new epilogue form against the uncounted wait.)
     constexpr int NST = TM * NIT;                       // stores a wave issues per epilogue
     static_assert(NST <= 60, "counted vmcnt");
     while (true) {
@@ -503,7 +510,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
         // 16-bit: this wave's pieces of stage 0 and its bias slice have landed once all but the previous epilogue's NST stores are
         // done (they were issued before them): the stores' acknowledgements drain under K tile 0 instead of being waited for here
         if constexpr (BDMA) {
+#ifdef DSIM_DEVTOOLS
+            if (first || (p.exp & 32768)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
             if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST) : "memory");
             first = false;
         }
@@ -618,8 +629,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
         // pieces beyond the slab's 16 rows carry an out-of-range lane part.
         const int mw0_u = em0 + wm_u * (BM / WM);
         const int nout0_u = (GEGLU ? ((en0 + wn_u * WBN) >> 1) : (en0 + wn_u * WBN)) - osel * p.out_split;
-        const int sbase = (mw0_u * p.ldo + nout0_u) * ES;               // scalar offset of slab 0
-        const int sslab = 16 * p.ldo * ES;                              // ... + i * sslab
+        // (unsigned: for an output just under the 2 GiB gemm_fill_extents accepts, the byte offset of the rows past M of a ragged last
+        //  tile exceeds INT_MAX -- it must wrap to an out-of-range offset, not be undefined)
+        const unsigned sbase = (unsigned)(mw0_u * p.ldo + nout0_u) * (unsigned)ES;      // scalar offset of slab 0
+        const unsigned sslab = 16u * (unsigned)p.ldo * (unsigned)ES;                    // ... + i * sslab
         unsigned lp[NIT];                                               // lane part of piece it
         int lrd[NIT];                                                   // its 16 bytes in the wave's LDS slab
         {
@@ -634,12 +647,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const GemmArgs p,
             }
         }
         auto piece_v = [&](int, int, int it) -> unsigned { return lp[it]; };
-        auto piece_s = [&](int i) -> int { return sbase + i * sslab; };
+        auto piece_s = [&](int i) -> int { return (int)(sbase + (unsigned)i * sslab); };
         // STORES add the scalar part to the vector offset instead (one v_add per piece): a buffer_store_dwordx4 with an SGPR soffset
         // reads its data registers late on gfx950, and hipcc (which pads the next VALU write of a wide store's data registers only
         // for a constant soffset) then lets e.g. the next piece's address arithmetic overwrite the first data dword -- seen as
         // address-like garbage in the first 4 bytes of 16-byte pieces, on the later-dispatched waves, timing dependent.
-        auto store_v = [&](int i, int it) -> unsigned { return lp[it] == OOB ? OOB : lp[it] + (unsigned)(sbase + i * sslab); };
+        auto store_v = [&](int i, int it) -> unsigned { return lp[it] == OOB ? OOB : lp[it] + sbase + (unsigned)i * sslab; };
         // residual prefetch: slab i's 16-byte pieces are requested before slab i is transposed, so the HBM latency
         // hides under the register phase instead of serialising the stores (at most 10 pieces in flight per lane:
         // the f32 parity mode would spill with all 20)

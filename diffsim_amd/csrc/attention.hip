@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 4 : 2)) void attn_short_v1_kernel(c
 //    image read the same prompt), so the 256-query level of the U-Net (d = 160: two blocks per batch element) amortises its staging
 //    over eight blocks like the others; block order [bkv][chunk][head]: the heads of a row stay neighbours on one XCD.
 template <int D, bool K80>
-__global__ __launch_bounds__(256, (D <= 80 ? 4 : 2)) void attn_short_kernel(const AttnArgs p, const float scale_log2, const int qit_) {
+__global__ __launch_bounds__(256, 2) void attn_short_kernel(const AttnArgs p, const float scale_log2, const int qit_) {
 #ifdef DSIM_DEVTOOLS
     const int qit = qit_ & 255, abl = qit_ >> 8;        // kbench ablations: 1 = no output stores, 2 = no Q prefetch loads (timing only)
 #else
@@ -1470,8 +1470,11 @@ __global__ void pair_finish_kernel(const float* __restrict__ part, int n_pairs, 
 inline float scale_log2_of(int D) { return (1.0f / sqrtf((float)D)) * 1.4426950408889634f; }
 
 #ifdef DSIM_DEVTOOLS
+// kbench occupancy probe: g_attn_lds_pad KB of unused LDS on top of every tiled attention launch
+#define A_LAUNCH_LDS(kern, base) ([&]() { const int l_ = (base) + g_attn_lds_pad * 1024; if (g_attn_lds_pad) (void)hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, l_); return l_; }())
 #define DSIM_SHORT_QIT(q) ((q) | (g_attn_dbg << 8))
 #else
+#define A_LAUNCH_LDS(kern, base) (base)
 #define DSIM_SHORT_QIT(q) (q)
 #endif
 
@@ -1485,19 +1488,23 @@ int launch_attn_d(const AttnArgs& a, hipStream_t s) {
     // costs more than the skipped maxima save
     if constexpr (sizeof(T) == 2 && (D == 40 || D == 64 || D == 80 || D == 160)) {
         // the prompt context of the cross-attentions (77 keys): keys resident in LDS, several query blocks per workgroup
-        // (interleaved A/B at 64 pairs: d = 40 0.502 -> 0.464 ms, d = 80 0.257 -> 0.227 ms; d = 160 at 256 queries: no gain, not used)
-        // (d = 64, SDXL, 32 pairs of rows: 1024 queries 0.055 -> 0.051 ms, 4096 queries 0.118 -> 0.123: the tiled kernel keeps those)
-        if (a.Nk <= 96 && g_attn_short && (D != 64 || a.Nq <= 1024)) {
-            constexpr int LDSS = 96 * (C::RS + C::RSV);
+        // (round 6, interleaved A/B against the tiled kernel at 64 pairs: d = 40 0.492 -> 0.387 ms, d = 80 0.221 -> 0.199, d = 160 at
+        //  256 queries 0.112 -> 0.091, SDXL's d = 64 at 4096 / 1024 queries 0.736 -> 0.652 / 0.397 -> 0.381)
+        if (a.Nk <= 96 && g_attn_short) {
+            // TWO workgroups per CU whatever the K / V images need: the kernel is bound by the cache-line operations of its Q rows in
+            // and O rows out, and more resident workgroups only thrash that path (64 pairs, ms at 4 | 3 | 2 | 1 workgroups per CU:
+            // d = 40  0.457 | 0.426 | 0.388 | 0.447;  d = 80  0.193 | 0.181 | 0.180 | 0.191: profiles/r06_experiments.txt 4e)
+            constexpr int LDSK = 96 * (C::RS + C::RSV);
+            constexpr int LDSS = LDSK < 56 * 1024 ? 56 * 1024 : LDSK;
 #ifdef DSIM_DEVTOOLS
             if (g_attn_short == 2) {
                 static DeviceOnce onces;
                 auto kern = attn_short_v1_kernel<D>;
-                CK_ONCE(onces, kern, LDSS);
+                CK_ONCE(onces, kern, LDSK);
                 const int nqb = (a.Nq + 127) / 128;
                 int qit = 8;
                 while (qit > 1 && (long)((nqb + qit - 1) / qit) * a.H * a.B < 8L * cu_count()) qit >>= 1;
-                hipLaunchKernelGGL(kern, dim3(((nqb + qit - 1) / qit) * a.H * a.B), dim3(256), LDSS, s, a, scale_log2_of(D), qit);
+                hipLaunchKernelGGL(kern, dim3(((nqb + qit - 1) / qit) * a.H * a.B), dim3(256), LDSK, s, a, scale_log2_of(D), qit);
                 DSIM_HIP_CHECK(hipGetLastError());
                 return DSIM_OK;
             }
@@ -1541,7 +1548,7 @@ int launch_attn_d(const AttnArgs& a, hipStream_t s) {
             static DeviceOnce once2;
             auto kern = attn_long_kernel<D, 0>;
             CK_ONCE(once2, kern, LDS3);
-            hipLaunchKernelGGL(kern, dim3(((a.Nq + 255) / 256) * a.H * a.B), dim3(256), LDS3, s, a, scale_log2_of(D));
+            hipLaunchKernelGGL(kern, dim3(((a.Nq + 255) / 256) * a.H * a.B), dim3(256), A_LAUNCH_LDS(kern, LDS3), s, a, scale_log2_of(D));
             DSIM_HIP_CHECK(hipGetLastError());
             return DSIM_OK;
         }
@@ -1554,12 +1561,12 @@ int launch_attn_d(const AttnArgs& a, hipStream_t s) {
                 static DeviceOnce o1;
                 auto k = attn_q2_kernel<D, true>;
                 CK_ONCE(o1, k, C::LDS);
-                hipLaunchKernelGGL(k, grid2, dim3(256), C::LDS, s, a, scale_log2_of(D));
+                hipLaunchKernelGGL(k, grid2, dim3(256), A_LAUNCH_LDS(k, C::LDS), s, a, scale_log2_of(D));
             } else {
                 static DeviceOnce o2;
                 auto k = attn_q2_kernel<D, false>;
                 CK_ONCE(o2, k, C::LDS);
-                hipLaunchKernelGGL(k, grid2, dim3(256), C::LDS, s, a, scale_log2_of(D));
+                hipLaunchKernelGGL(k, grid2, dim3(256), A_LAUNCH_LDS(k, C::LDS), s, a, scale_log2_of(D));
             }
             DSIM_HIP_CHECK(hipGetLastError());
             return DSIM_OK;
@@ -1569,12 +1576,12 @@ int launch_attn_d(const AttnArgs& a, hipStream_t s) {
         static DeviceOnce oncef;
         auto kern = attn_kernel<T, D, true>;
         CK_ONCE(oncef, kern, C::LDS);
-        hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS, s, a, scale_log2_of(D));
+        hipLaunchKernelGGL(kern, grid, dim3(256), A_LAUNCH_LDS(kern, C::LDS), s, a, scale_log2_of(D));
     } else {
         static DeviceOnce once;
         auto kern = attn_kernel<T, D, false>;
         CK_ONCE(once, kern, C::LDS);
-        hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS, s, a, scale_log2_of(D));
+        hipLaunchKernelGGL(kern, grid, dim3(256), A_LAUNCH_LDS(kern, C::LDS), s, a, scale_log2_of(D));
     }
     DSIM_HIP_CHECK(hipGetLastError());
     return DSIM_OK;
@@ -1625,6 +1632,7 @@ int launch_tail_t(const void* q, const void* k, const void* v, const int32_t* ia
 #ifdef DSIM_DEVTOOLS
 int g_attn_q2 = 1;
 int g_attn_dbg = 0;
+int g_attn_lds_pad = 0;
 int g_attn_short = 1;
 int g_attn_fast_min = 1024;
 int g_tail160 = 1;
@@ -1640,7 +1648,7 @@ int g_sdpa160 = 1;
 const char* attention_kernel_kind(const AttnArgs& a, int dtype) {
     if (dtype == DSIM_F32) return "";
     if (g_sdpa160 && sdpa160_applies(a)) return "_p160";
-    if ((a.D == 40 || a.D == 80 || a.D == 160 || (a.D == 64 && a.Nq <= 1024)) && a.Nk <= 96) return "_short";
+    if ((a.D == 40 || a.D == 64 || a.D == 80 || a.D == 160) && a.Nk <= 96) return "_short";
     if (a.D == 40 && a.Nk >= 2048 && a.Nk % KT == 0) return "_long";
     if (a.D == 64 && a.Nk > 96 && a.Nq >= 256) return a.Nk >= g_attn_fast_min ? "_q2fast" : "_q2";
     if (a.Nk >= g_attn_fast_min) return "_fast";

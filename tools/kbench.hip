@@ -351,6 +351,20 @@ static void bench_attn(const char* name, int B, int Bkv, int H, int Nq, int Nk, 
         }
         printf("  32 queries per wave %8.3f/%8.3f ms | 64 queries per wave %8.3f/%8.3f ms (min/median)\n", q1[0], q1[rounds / 2], q2[0], q2[rounds / 2]);
     }
+    if (const char* e = getenv("KB_ATTNPAD")) {          // occupancy probe: KB of unused LDS per workgroup (tiled kernels)
+        std::string l = e;
+        for (size_t pos = 0; pos < l.size();) {
+            size_t nx = l.find(',', pos);
+            if (nx == std::string::npos) nx = l.size();
+            g_attn_lds_pad = atoi(l.substr(pos, nx - pos).c_str());
+            std::vector<float> qa;
+            for (int r = 0; r < rounds; ++r) qa.push_back(t.run([&] { st = launch_attention(a, DSIM_BF16, 0); }, iters));
+            std::sort(qa.begin(), qa.end());
+            printf("  +%d KB of LDS per workgroup: %8.3f ms (st=%d)\n", g_attn_lds_pad, qa[rounds / 2], st);
+            pos = nx + 1;
+        }
+        g_attn_lds_pad = 0;
+    }
     std::sort(m0.begin(), m0.end()); std::sort(m1.begin(), m1.end());
     const float ms = m1[rounds / 2];
     const double fl = 4.0 * B * H * (double)Nq * Nk * D;

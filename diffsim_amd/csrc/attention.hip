@@ -1633,6 +1633,7 @@ int launch_tail_t(const void* q, const void* k, const void* v, const int32_t* ia
 int g_attn_q2 = 1;
 int g_attn_dbg = 0;
 int g_attn_lds_pad = 0;
+int g_norm_lds_pad = 0;
 int g_attn_short = 1;
 int g_attn_fast_min = 1024;
 int g_tail160 = 1;

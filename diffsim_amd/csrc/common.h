@@ -174,6 +174,7 @@ extern int g_ln_rows;           // DSIM_LN_ROWS
 extern int g_prep8;             // DSIM_PREP8
 extern int g_attn_q2;           // 0 = long-key attention with one query block per wave (attn_kernel)
 extern int g_attn_dbg;          // ablation mask of attn_long_kernel
+extern int g_norm_lds_pad;      // kbench occupancy probe: KB of unused LDS per GroupNorm workgroup
 extern int g_attn_lds_pad;      // kbench occupancy probe: KB of unused LDS added to the tiled attention launches
 extern int g_attn_short;        // 0 = short key sequences through attn_kernel
 extern int g_attn_fast_min;     // fewest keys that take the fixed-reference softmax of attn_kernel

@@ -712,6 +712,13 @@ int gn_onepass_slab(int C0, int C1, int B, int HW, int groups) {
     return best;
 }
 
+#ifdef DSIM_DEVTOOLS
+// (g_norm_lds_pad: kbench occupancy probe, KB of unused LDS per GroupNorm workgroup; defined in attention.hip)
+#define GN_PAD ((size_t)g_norm_lds_pad * 1024)
+#else
+#define GN_PAD ((size_t)0)
+#endif
+
 template <typename T, int NS, int UNR>
 int gn_launch(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta, void* out, int B,
               int HW, int groups, float eps, int silu, void* scratch, int chunks, int rb, size_t lds, hipStream_t s,
@@ -722,9 +729,9 @@ int gn_launch(const void* x0, int C0, const void* x1, int C1, const float* gamma
         hipLaunchKernelGGL(gn_fold_kernel, dim3(groups, B), dim3(GN_THREADS), 0, s, pre, pre_chunks, (C0 + C1) / 4, groups, (double*)scratch);
         chunks = 1;
     } else
-    hipLaunchKernelGGL((gn_stats_kernel<T, NS, UNR>), dim3(chunks, B), dim3(GN_THREADS), lds, s, (const T*)x0, C0,
+    hipLaunchKernelGGL((gn_stats_kernel<T, NS, UNR>), dim3(chunks, B), dim3(GN_THREADS), lds + GN_PAD, s, (const T*)x0, C0,
                        (const T*)x1, C1, HW, groups, (double*)scratch);
-    const size_t alds = (size_t)chunks * groups * 2 * sizeof(double);       // <= 32 KB
+    const size_t alds = (size_t)chunks * groups * 2 * sizeof(double) + GN_PAD;       // <= 32 KB
     if (silu)
         hipLaunchKernelGGL((gn_apply_kernel<T, true, NS, UNR>), dim3(rb, B), dim3(GN_THREADS), alds, s, (const T*)x0, C0,
                            (const T*)x1, C1, gamma, beta, (T*)out, HW, groups, eps, chunks, (const double*)scratch);

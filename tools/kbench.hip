@@ -620,6 +620,21 @@ static void bench_gn(const char* name, int B, int HW, int C, int iters, Timer& t
     HC(hipMalloc(&out, (size_t)B * HW * C * 2));
     HC(hipMalloc(&sc, groupnorm_scratch_bytes(B, 32)));
     int st = DSIM_OK;
+    if (const char* e = getenv("KB_NORMPAD")) {
+        std::string l = e;
+        int st2 = 0;
+        for (size_t pos = 0; pos < l.size();) {
+            size_t nx = l.find(',', pos);
+            if (nx == std::string::npos) nx = l.size();
+            g_norm_lds_pad = atoi(l.substr(pos, nx - pos).c_str());
+            std::vector<float> qa;
+            for (int r = 0; r < 5; ++r) qa.push_back(t.run([&] { st2 = launch_groupnorm(x, C, nullptr, 0, g, b, out, B, HW, 32, 1e-5f, 1, DSIM_BF16, sc, 0); }, iters));
+            std::sort(qa.begin(), qa.end());
+            printf("  %s +%d KB of LDS per workgroup: %8.4f ms (st=%d)\n", name, g_norm_lds_pad, qa[2], st2);
+            pos = nx + 1;
+        }
+        g_norm_lds_pad = 0;
+    }
     const float ms = t.run([&] { st = launch_groupnorm(x, C, nullptr, 0, g, b, out, B, HW, 32, 1e-5f, 1, DSIM_BF16, sc, 0); }, iters);
     if (getenv("KB_GN_SILU")) {      // with and without the SiLU, interleaved: is the apply pass VALU-limited?
         std::vector<float> a, c;

@@ -184,6 +184,7 @@ extern float* g_tail160_dbg;    // kbench: device buffer for the first unit's tw
 extern int g_tail160_exp;       // kbench: experiment mask of pair_tail160_kernel
 extern int g_ff_dbg;            // ablation mask of the fused feed-forward kernel (rowres.hip)
 extern int g_rl_dbg;            // ablation mask of the row-resident Linear kernel (rowres.hip)
+extern int g_rl_wpc;            // rowlin_kernel's persistent workgroups per CU (kbench occupancy probe)
 extern int g_ff_stagger;        // its wave de-phasing, in s_nop 7 units per wave index
 #else
 constexpr int g_gemm_skinny = 1, g_gemm_persistent = 1, g_force_bm = 0, g_gn_onepass = 1, g_ln_rows = 1, g_prep8 = 1, g_attn_q2 = 1, g_attn_short = 1, g_attn_fast_min = 1024, g_tail160 = 1, g_sdpa160 = 1;

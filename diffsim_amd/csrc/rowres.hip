@@ -548,6 +548,7 @@ __global__ __launch_bounds__(256, 3) void rowlin_kernel(const RLParams p, const 
 int g_rl_dbg = 0;
 int g_ff_dbg = 0;
 int g_ff_stagger = -1;     // -1 = the product default
+int g_rl_wpc = 3;          // rowlin_kernel's persistent workgroups per CU
 #endif
 
 size_t ff_stream_bytes(int C) { return C == RC ? (size_t)RITER * RCHB : 0; }
@@ -619,7 +620,12 @@ int launch_rowlin(const RowLinArgs& a, hipStream_t s) {
     p.x_bytes = (unsigned)((size_t)a.M * RC * 2); p.out_bytes = (unsigned)((size_t)a.M * a.N * 2);
     p.stream_bytes = (unsigned)rowlin_stream_bytes(a.C, a.N);
     const int ntiles = (a.M + 127) / 128;
-    const int grid = ntiles < 3 * cu_count() ? ntiles : 3 * cu_count();
+#ifdef DSIM_DEVTOOLS
+    const int wpc = g_rl_wpc;        // kbench occupancy probe: workgroups per CU
+#else
+    constexpr int wpc = 3;
+#endif
+    const int grid = ntiles < wpc * cu_count() ? ntiles : wpc * cu_count();
 #ifdef DSIM_DEVTOOLS
     switch (g_rl_dbg) {
 #define X(d) case d: { static DeviceOnce o; auto k = rowlin_kernel<d>; CK_ONCE(o, k, LLDS); hipLaunchKernelGGL(k, dim3(grid), dim3(256), LLDS, s, p, ntiles); DSIM_HIP_CHECK(hipGetLastError()); return DSIM_OK; }

@@ -794,6 +794,14 @@ static void bench_rowlin(const char* name, int M, int N, bool ln, int iters, Tim
     float lnm = 0.f;
     if (ln) { std::sort(ml.begin(), ml.end()); lnm = ml[rounds / 2]; }
     const double fl = 2.0 * M * (double)C * N;
+    for (int wpc = 1; wpc <= 3; ++wpc) {
+        g_rl_wpc = wpc;
+        std::vector<float> qa;
+        for (int r = 0; r < 5; ++r) qa.push_back(t.run([&] { s1 |= launch_rowlin(a, 0); }, iters));
+        std::sort(qa.begin(), qa.end());
+        printf("  rowlin with %d workgroups per CU: %7.3f ms\n", wpc, qa[2]);
+    }
+    g_rl_wpc = 3;
     printf("%-26s M=%7d  rowlin %7.3f ms %6.1f TF | ln %6.3f + gemm %6.3f = %7.3f ms   maxdiff %.4g  st=%d/%d\n", name, M, mf[rounds / 2],
            fl / mf[rounds / 2] / 1e9, lnm, mg[rounds / 2], lnm + mg[rounds / 2], d, s0, s1);
     HC(hipFree(x)); HC(hipFree(w)); HC(hipFree(b)); HC(hipFree(lg)); HC(hipFree(lb));

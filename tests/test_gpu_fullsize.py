@@ -262,11 +262,18 @@ def test_sdxl_ragged_side_26():
     taps = (("up_blocks", [0, 0, 0]), ("up_blocks", [1, 2, 1]), ("down_blocks", [1, 1, 0]))
     f64 = torch.float64
     want = {}
-    for ti, (blk, tl) in enumerate(taps):
-        for i in (0, npairs - 1):
-            fa = R.features_xl(unet, zA[i:i + 1], nA, ctx, pooled, 600, blk, tl)
-            fb = R.features_xl(unet, zB[i:i + 1], nB, ctx, pooled, 600, blk, tl)
-            want[(ti, i)] = float(R.pair_score(*[f.to(f64) for f in fa], *[f.to(f64) for f in fb], "cosine"))
+    # ONE oracle forward per image serves the three taps (hooks in execution order: the down-path tap, the 7 x 7 level, the 13 x 13
+    # level behind the upsample -- what R.features_xl computes per tap, without re-running the graph in front of each)
+    order = (2, 0, 1)
+    added = {"text_embeds": pooled, "time_ids": R.sdxl_time_ids(unet.cfg).repeat(2, 1)}
+
+    def feats(z, nz):
+        x, t = R.sdxl_inputs(z, nz, 600)
+        return _qkv_at_taps(R, unet, torch.cat([x] * 2), t, ctx, added, {ti: taps[ti] for ti in order})
+    for i in (0, npairs - 1):
+        fa, fb = feats(zA[i:i + 1], nA), feats(zB[i:i + 1], nB)
+        for ti in range(len(taps)):
+            want[(ti, i)] = float(R.pair_score(*[f.to(f64) for f in fa[ti]], *[f.to(f64) for f in fb[ti]], "cosine"))
     del unet
     xl = diffsim_xl(torch.float32, "cuda", unet_config=cfg, state_dict=sd)
     for ti, (blk, tl) in enumerate(taps):
